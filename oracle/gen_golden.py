@@ -1,0 +1,376 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz from the REFERENCE ITSELF (runs only in the build container, where
+/root/reference exists; never on the GPU box).  Test infrastructure only.
+
+What runs from the reference (imported from where it lies, nothing copied):
+  * pointllm.model.{PointTransformer, PointLLMLlamaForCausalLM, PointLLMConfig}  (PointBERT, splice,
+    lm_head), through them HF transformers' LLaMA (third-party, installed 5.15.0)
+  * model_arch.TrajPointLLMForCausalLM  (freeze logic, forward, generate)
+  * egoscaler/models/utils/{traj_utils,metrics}.py
+  * single functions whose MODULE cannot be imported as released (ordinary Python errors: open3d
+    missing for pcm_tools; AttributeError at utils/utils.py:10): the function objects are compiled
+    from the reference file in memory with `ast` (see _functions_from) and called; no text is kept.
+Missing pure-Python deps are replaced by oracle/_shims (README there).
+
+Harness-level adaptations (do not change arithmetic):
+  * FPS start index: `torch.randint` is replaced for the duration of a call by a function that
+    returns the seeded start vector (reference: misc.py:52 draws it from the global RNG).
+  * tiny PointBERT: `cfg_from_yaml_file` is wrapped so that the config NAME "tiny" yields an
+    in-memory config (the reference reads YAML next to its own sources, which are read-only).
+
+Usage:  python oracle/gen_golden.py            (writes tests/golden/, prints oracle-vs-reference diffs)
+"""
+import ast
+import contextlib
+import json
+import os
+import sys
+import tempfile
+import types
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+sys.path[:0] = [os.path.join(ROOT, "oracle", "_shims"), os.path.join(REF, "egoscaler/models/pointllm"), REF, ROOT]
+
+from egoscaler_amd import synth                                   # noqa: E402
+from egoscaler_amd.config import dims_tiny, dims_7b, PointBertDims  # noqa: E402
+from oracle import pointbert as OPB, llama as OL, pointllm as OPL, pointcloud as OPC, traj as OT  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+os.makedirs(GOLD, exist_ok=True)
+torch.set_grad_enabled(True)
+torch.set_num_threads(8)
+
+
+def _functions_from(path, names, glb):
+    """Compile selected top-level functions of a reference file in memory and return them."""
+    tree = ast.parse(open(path).read(), filename=path)
+    keep = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in names]
+    mod = ast.Module(body=keep, type_ignores=[])
+    ns = dict(glb)
+    exec(compile(mod, path, "exec"), ns)
+    return [ns[n] for n in names]
+
+
+@contextlib.contextmanager
+def fixed_fps_start(start):
+    orig = torch.randint
+
+    def fake(*a, **k):
+        return torch.as_tensor(start, dtype=torch.long).clone()
+    torch.randint = fake
+    try:
+        yield
+    finally:
+        torch.randint = orig
+
+
+def rel(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+
+
+def set_mismatch(a, b):
+    """a,b [...,k] index sets -> number of rows whose sets differ."""
+    return int((np.sort(a, -1) != np.sort(b, -1)).any(-1).sum())
+
+
+# -------------------------------------------------------------------------------------------------
+def gen_pointcloud():
+    (gpc,) = _functions_from(os.path.join(REF, "egoscaler/data/tools/pcm_tools.py"), ["get_points_colors"], {"np": np})
+    H = W = 32
+    rgb, depth = synth.synth_clip(7, 2, H, W)
+    f, pp = synth.clip_intrinsics(H)
+    out = {}
+    for t in range(2):
+        rgbd = np.concatenate([rgb[t], depth[t][..., None]], -1)
+        for tag, boxes in (("", None), ("_box", [{"box": {"ymin": 3, "ymax": 11, "xmin": 5, "xmax": 20}}])):
+            p, c = gpc(rgbd, boxes, W, H, pp, f, f, d_thres=synth.DEPTH_THRESHOLD)
+            ob = None if boxes is None else [b["box"] for b in boxes]
+            po, co, _ = OPC.unproject_frame(rgbd, W, H, pp, f, f, synth.DEPTH_THRESHOLD, ob)
+            assert p.dtype == np.float64 and c.dtype == np.float32, (p.dtype, c.dtype)
+            assert np.array_equal(p, po) and np.array_equal(c, co), "oracle unproject != reference"
+            out[f"points{t}{tag}"] = p
+            out[f"colors{t}{tag}"] = c
+    # no depth threshold variant
+    p, c = gpc(rgbd, None, W, H, pp, f, f, d_thres=None)
+    po, co, _ = OPC.unproject_frame(rgbd, W, H, pp, f, f, None, None)
+    assert np.array_equal(p, po) and np.array_equal(c, co)
+    out["points_nothres"] = p
+    # pc_norm (pointllm/data/utils.py imports cleanly? it pulls transformers etc.; use ast too)
+    (pcn,) = _functions_from(os.path.join(REF, "egoscaler/models/pointllm/pointllm/data/utils.py"), ["pc_norm"], {"np": np})
+    pc = np.concatenate([out["points0"], out["colors0"].astype(np.float64)], 1)
+    ref = pcn(pc)
+    assert np.array_equal(ref, OPC.pc_norm(pc))
+    out["pc_norm0"] = ref
+    out["meta"] = np.array([H, W, 7, 2], dtype=np.int64)
+    np.savez_compressed(os.path.join(GOLD, "pointcloud.npz"), **out)
+    print("pointcloud.npz: oracle == reference bit-exact (A1, A2)")
+
+
+# -------------------------------------------------------------------------------------------------
+def gen_traj():
+    from egoscaler.models.utils import traj_utils as RT, metrics as RM
+    cam = types.SimpleNamespace()
+    glb = {"np": np, "re": __import__("re"), "PINHOLE_IMAGE_HEIGHT": 1408, "PINHOLE_IMAGE_WIDTH": 1408}
+    from egoscaler.configs.camera import CameraConfig
+    glb["FOCAL_LEN"] = CameraConfig.devices.aria.focal_len          # utils.py:10 reads a misspelt attribute
+    glb["PRICIPAL_POINT"] = CameraConfig.devices.aria.principal_point
+    path = os.path.join(REF, "egoscaler/models/pointllm/utils/utils.py")
+    names = ["discretize_action", "token_to_action", "rt2_scaler", "str_to_float"]
+    glb2 = dict(glb)
+    fns = _functions_from(path, names, glb2)
+    disc, t2a, rt2, s2f = fns
+    # str_to_float calls token_to_action / rt2_scaler by global name
+    for f_ in fns:
+        f_.__globals__.update({n: fn for n, fn in zip(names, fns)})
+    out = {}
+    g = np.random.default_rng(3)
+    v = np.concatenate([[-1, -0.999, 0, 0.5, 1, 1.2, -1.2], g.uniform(-1.1, 1.1, 64)])
+    for nb in (256, 16):
+        r = np.array(disc(v, nb))
+        assert np.array_equal(r, np.array(OT.discretize_action(v, nb)))
+        out[f"digitize_{nb}"] = r
+    out["digitize_in"] = v
+    toks = g.integers(0, 256, 40)
+    assert np.array_equal(np.array(t2a(toks)), np.array(OT.token_to_action(toks)))
+    out["t2a_in"], out["t2a_out"] = toks, np.array(t2a(toks))
+    tr = g.uniform(-1, 1, (9, 6)).astype(np.float32)
+    a = rt2(tr.copy(), [2.5, 0.1], "val")
+    b = OT.rt2_scaler(tr.copy(), [2.5, 0.1])
+    assert np.array_equal(a, b)
+    out["rt2_in"], out["rt2_out"] = tr, a
+    # string parsing with a malformed segment in the middle and one in front
+    segs = []
+    bins = g.integers(0, 256, (6, 6))
+    for i, row in enumerate(bins):
+        segs.append("garbage" if i in (0, 3) else " ".join(f"<p{x}>" for x in row))
+    s = "<ts> " + " <tsep> ".join(segs) + " <tsep> <te>"
+    a = s2f(s, [2.5, 0.1], "val", rt2=True)
+    raw = OT.parse_traj_string(s)
+    b = OT.rt2_scaler(raw.copy(), [2.5, 0.1])
+    assert np.array_equal(a, b), (a, b)
+    out["parse_out"] = a
+    json.dump({"parse_in": s}, open(os.path.join(GOLD, "traj_strings.json"), "w"))
+    assert s2f("nothing here", [2.5, 0.1], "val", rt2=True) is None and OT.parse_traj_string("nothing here") is None
+    # resample / smoothing / metrics from the importable reference modules
+    for T in (50, 20, 7, 3, 2, 1):
+        t = g.normal(size=(T, 6))
+        r = RT.preprocess_traj(t, 20)
+        assert np.array_equal(r, OT.preprocess_traj(t, 20))
+        out[f"pre_in_{T}"], out[f"pre_out_{T}"] = t, r
+        r = RT.smoothing_traj(t)
+        assert np.allclose(r, OT.smoothing_traj(t), rtol=0, atol=0)
+        out[f"smooth_out_{T}"] = r
+    gen, gt = g.normal(size=(15, 6)), g.normal(size=(20, 6))
+    out["m_gen"], out["m_gt"] = gen, gt
+    out["ade"] = np.array(RM.average_displacement_error(gen, gt))
+    out["fde"] = np.array(RM.final_displacement_error(gen, gt))
+    g20 = g.normal(size=(20, 6))
+    out["m_gen20"] = g20
+    out["ade_as_called"] = np.array(RM.average_displacement_error(g20[None], gt[None]))
+    assert abs(out["ade"] - OT.ade(gen, gt)) == 0 and abs(out["fde"] - OT.fde(gen, gt)) == 0
+    assert abs(out["ade_as_called"] - OT.ade_as_called(g20, gt)) == 0
+    np.savez_compressed(os.path.join(GOLD, "traj.npz"), **out)
+    print("traj.npz: oracle == reference (A14)")
+
+
+# -------------------------------------------------------------------------------------------------
+def _pb_cfg(pb: PointBertDims):
+    from easydict import EasyDict
+    return EasyDict(model=dict(NAME="PointTransformer", trans_dim=pb.trans_dim, depth=pb.depth, drop_path_rate=0.1,
+                               cls_dim=40, num_heads=pb.num_heads, group_size=pb.group_size, num_group=pb.num_group,
+                               encoder_dims=pb.encoder_dims, point_dims=3, projection_hidden_layer=len(pb.projection_hidden_dim),
+                               projection_hidden_dim=list(pb.projection_hidden_dim), use_max_pool=False), npoints=pb.npoints)
+
+
+def gen_pointbert_full():
+    """Real YAML (8192 pts, 512 groups of 32): FPS / kNN indices for B=2, encoder output for B=1."""
+    from pointllm.model import PointTransformer
+    from pointllm.utils import cfg_from_yaml_file
+    from pointllm.model.pointbert import dvae, misc
+    dims = dims_7b()
+    pb = dims.pb
+    cfg = cfg_from_yaml_file(os.path.join(REF, "egoscaler/models/pointllm/pointllm/model/pointbert/PointTransformer_8192point_2layer.yaml"))
+    cfg.model.point_dims = 6
+    net = PointTransformer(cfg.model, use_max_pool=False).eval()
+    sd = {k: synth.synth_tensor("model.point_backbone." + k, v.shape, 0) for k, v in net.state_dict().items()}
+    mine = dict(synth.pointbert_param_shapes(pb))
+    assert set(mine) == set(sd) and all(tuple(sd[k].shape) == tuple(mine[k]) for k in sd), "state-dict layout differs"
+    net.load_state_dict(sd, strict=True)
+    pts = torch.stack([synth.synth_cloud(dims, i) for i in range(2)])
+    start = np.array([0, 4097])
+    with fixed_fps_start(start), torch.no_grad():
+        center = misc.fps(pts[:, :, :3].contiguous(), pb.num_group)
+        kidx = dvae.knn_point(pb.group_size, pts[:, :, :3].contiguous(), center)
+        nb_ref, center2 = net.group_divider(pts)
+    with fixed_fps_start(start[:1]), torch.no_grad():
+        feats = net(pts[:1])
+    fidx = OPB.fps_indices(pts[:, :, :3].numpy(), pb.num_group, start)
+    cen_o = np.take_along_axis(pts[:, :, :3].numpy(), fidx[:, :, None].repeat(3, 2), 1)
+    assert np.array_equal(cen_o, center.numpy()), "FPS oracle != reference"
+    ko = OPB.knn_indices(pts[:, :, :3].numpy(), cen_o, pb.group_size)
+    mm = set_mismatch(ko, kidx.numpy())
+    print(f"pointbert_full: FPS bit-exact; kNN set mismatches {mm}/{ko.shape[0] * ko.shape[1]} groups")
+    sdp = {"model.point_backbone." + k: v for k, v in sd.items()}
+    taps = {}
+    fo = OPB.point_transformer(sdp, "model.point_backbone.", pts[:1], pb, start[:1], taps)
+    print("   encoder out rel err oracle vs reference:", rel(fo.numpy(), feats.numpy()))
+    np.savez_compressed(os.path.join(GOLD, "pointbert_full.npz"),
+                        fps_start=start, fps_idx=fidx.astype(np.int16),
+                        knn_sets=np.sort(kidx.numpy(), -1).astype(np.int16),
+                        center=center.numpy(), features_b0=feats.numpy().astype(np.float32))
+
+
+def gen_tiny_model():
+    import pointllm.model.pointllm as RPL
+    from pointllm.model import PointLLMLlamaForCausalLM, PointLLMConfig
+    import model_arch as RMA
+    dims = dims_tiny()
+    lm, pb, tok = dims.lm, dims.pb, dims.tok
+    orig_cfg = RPL.cfg_from_yaml_file
+
+    def cfg_hook(path):
+        return _pb_cfg(pb) if os.path.basename(path) == "tiny.yaml" else orig_cfg(path)
+    RPL.cfg_from_yaml_file = cfg_hook
+    cfg = PointLLMConfig(hidden_size=lm.hidden_size, intermediate_size=lm.intermediate_size,
+                         num_hidden_layers=lm.num_hidden_layers, num_attention_heads=lm.num_attention_heads,
+                         num_key_value_heads=lm.num_attention_heads, vocab_size=lm.vocab_size,
+                         rms_norm_eps=lm.rms_norm_eps, max_position_embeddings=lm.max_position_embeddings,
+                         pad_token_id=tok.pad, bos_token_id=tok.bos, eos_token_id=tok.eos,
+                         point_backbone="PointBERT", point_backbone_config_name="tiny", use_color=True,
+                         mm_use_point_start_end=True, DEFAULT_POINT_PATCH_TOKEN="<point_patch>",
+                         DEFAULT_POINT_START_TOKEN="<point_start>", DEFAULT_POINT_END_TOKEN="<point_end>",
+                         tie_word_embeddings=False, attn_implementation="eager")
+    base = PointLLMLlamaForCausalLM(cfg)
+    sd = synth.synth_state_dict(dims, 0)
+    missing = set(base.state_dict()) ^ set(sd)
+    assert not missing, f"state-dict key mismatch: {sorted(missing)[:8]}"
+    base.load_state_dict(sd, strict=True)
+    tmp = tempfile.mkdtemp()
+    base.save_pretrained(tmp)
+    args = types.SimpleNamespace(unfreeze_pc_encoder=False, unfreeze_language_model=True, model_name=tmp, num_bins=tok.num_bins)
+    model = RMA.TrajPointLLMForCausalLM(args, cfg, tmp)
+    model.load_state_dict(sd, strict=True)
+    pbc = model.get_model().point_backbone_config
+    pbc.update(point_patch_token=tok.point_patch, point_start_token=tok.point_start, point_end_token=tok.point_end)
+
+    B = 2
+    toks, masks, Lp = synth.synth_batch(dims, B, text_len=8, num_steps=4, max_traj_token=40)
+    pts = torch.stack([synth.synth_cloud(dims, i) for i in range(B)])
+    start = np.array([0, 17])
+    out = {"tokens": toks.numpy(), "masks": masks.numpy(), "prompt_len": np.array(Lp), "fps_start": start}
+
+    # ---- forward + loss + backward (train mode: backbone stays eval, model_arch.py:110-124)
+    model.train()
+    with fixed_fps_start(start):
+        o = model(input_ids=toks, attention_mask=masks, point_clouds=pts, return_dict=True)
+    logits = o.logits
+    lg = logits[:, Lp - 1:-1, :]
+    tg = toks[:, Lp:]
+    loss = F.cross_entropy(lg.reshape(-1, lg.shape[-1]), tg.flatten(), ignore_index=tok.pad)   # train.py:174-181
+    loss.backward()
+    grads = {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+    assert not any(n.startswith("model.point_backbone") for n in grads)
+    # hidden states via a second eval pass with hooks
+    model.eval()
+    hid = {}
+    hooks = [l.register_forward_hook(lambda m, i, o_, k=k: hid.__setitem__(k, (o_[0] if isinstance(o_, tuple) else o_).detach()))
+             for k, l in enumerate(model.model.layers)]
+    feats_tap = {}
+    hooks.append(model.model.point_proj.register_forward_hook(lambda m, i, o_: feats_tap.setdefault("pf", o_.detach())))
+    hooks.append(model.model.point_backbone.register_forward_hook(lambda m, i, o_: feats_tap.setdefault("pb", o_.detach())))
+    with fixed_fps_start(start), torch.no_grad():
+        o2 = model(input_ids=toks, attention_mask=masks, point_clouds=pts, return_dict=True)
+    for h in hooks:
+        h.remove()
+    assert torch.equal(o2.logits, logits.detach())
+
+    # ---- oracle comparison
+    sd_o = {k: v.clone().requires_grad_(v.dtype.is_floating_point and not k.startswith("model.point_backbone")) for k, v in sd.items()}
+    taps = {}
+    lo = OPL.forward(sd_o, dims, toks, masks, pts, start, taps=taps)
+    loss_o = OL.traj_loss(lo, toks, Lp, tok.pad)
+    loss_o.backward()
+    print("tiny_model: logits rel", rel(lo.detach(), logits.detach()), " loss", float(loss), float(loss_o))
+    print("   pointbert rel", rel(taps["point_features"].detach(), feats_tap["pf"]))
+    for k in range(lm.num_hidden_layers):
+        print(f"   layer{k} rel", rel(taps[f"layer{k}"].detach(), hid[k]))
+    worst = max(rel(sd_o[n].grad, g) for n, g in grads.items())
+    print("   worst grad rel over", len(grads), "tensors:", worst)
+
+    out.update(logits=logits.detach().numpy(), loss=np.array(float(loss)),
+               point_backbone_out=feats_tap["pb"].numpy(), point_features=feats_tap["pf"].numpy())
+    for k in range(lm.num_hidden_layers):
+        out[f"hidden{k}"] = hid[k].numpy()
+    keep = ["model.embed_tokens.weight", "lm_head.weight", "model.norm.weight",
+            "model.point_proj.0.weight", "model.point_proj.0.bias", "model.point_proj.4.weight", "model.point_proj.4.bias",
+            "model.layers.0.self_attn.q_proj.weight", "model.layers.0.self_attn.k_proj.weight",
+            "model.layers.0.self_attn.v_proj.weight", "model.layers.0.self_attn.o_proj.weight",
+            "model.layers.1.mlp.gate_proj.weight", "model.layers.1.mlp.up_proj.weight", "model.layers.1.mlp.down_proj.weight",
+            "model.layers.0.input_layernorm.weight", "model.layers.1.post_attention_layernorm.weight"]
+    for n in keep:
+        out["grad:" + n] = grads[n].numpy()
+    out["grad_names_all"] = np.array(sorted(grads))
+
+    # ---- frozen-LLM mode: which tensors get gradients (model_arch.py:33-51)
+    args_f = types.SimpleNamespace(unfreeze_pc_encoder=False, unfreeze_language_model=False, model_name=tmp, num_bins=tok.num_bins)
+    mf = RMA.TrajPointLLMForCausalLM(args_f, cfg, tmp)
+    out["trainable_frozen_llm"] = np.array(sorted(n for n, p in mf.named_parameters() if p.requires_grad))
+    out["trainable_unfrozen_llm"] = np.array(sorted(n for n, p in model.named_parameters() if p.requires_grad))
+
+    # ---- greedy generation.  The released generate() path cannot be used as the pin:
+    #   (a) model_arch.py:69-74 forwards only input_ids/attention_mask/point_clouds, so the KV cache
+    #       that prepare_inputs_for_generation (pointllm.py:255-275) hands back is dropped and every
+    #       step after the first sees ONE token with no context;
+    #   (b) under the installed transformers 5.15 `if past_key_values:` (pointllm.py:258) is already
+    #       true at step 0 (an empty DynamicCache object), so even the prompt is cut to its last token.
+    # The intended behaviour (prefill with encoder+splice, then cached single-token
+    # steps) equals re-running the reference's own forward() on the growing sequence, which is what
+    # pins it here: argmax of the last position, appended, T times.
+    model.eval()
+    prompts, pmask = toks[:, :Lp], masks[:, :Lp]
+    seq, msk, sc = prompts, pmask, []
+    for t in range(10):
+        with fixed_fps_start(start), torch.no_grad():
+            lg_t = model(input_ids=seq, attention_mask=msk, point_clouds=pts, return_dict=True).logits[:, -1, :]
+        sc.append(lg_t)
+        seq = torch.cat([seq, lg_t.argmax(-1, keepdim=True)], 1)
+        msk = torch.cat([msk, torch.ones_like(msk[:, :1])], 1)
+    scores = torch.stack(sc, 1)
+    so, sco = OPL.greedy_generate(sd, dims, prompts, pmask, pts, start, 10)
+    print("   generate: sequences equal", bool(torch.equal(so, seq)), " scores rel", rel(torch.stack(sco, 1), scores))
+    out.update(gen_sequences=seq.numpy(), gen_scores=scores.numpy())
+
+    # ---- splice error behaviour (pointllm.py:146-151)
+    bad = toks.clone()
+    bad[0, (bad[0] == tok.point_end).nonzero()[0, 0]] = 5
+    for name, t in (("missing_end", bad),):
+        try:
+            with fixed_fps_start(start), torch.no_grad():
+                model(input_ids=t, attention_mask=masks, point_clouds=pts, return_dict=True)
+            raised = "none"
+        except ValueError as e:
+            raised = str(e)
+        out["err_" + name] = np.array(raised)
+        try:
+            OPL.splice_positions(t, tok, pb.point_token_len)
+            ro = "none"
+        except ValueError as e:
+            ro = str(e)
+        assert ro == raised, (ro, raised)
+    np.savez_compressed(os.path.join(GOLD, "tiny_model.npz"), **out)
+    RPL.cfg_from_yaml_file = orig_cfg
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["pointcloud", "traj", "pointbert_full", "tiny_model"]
+    for w in which:
+        globals()["gen_" + w]()
+    sizes = {f: os.path.getsize(os.path.join(GOLD, f)) for f in sorted(os.listdir(GOLD))}
+    print("fixtures:", sizes)
