@@ -1,0 +1,47 @@
+"""ctypes binding of libegomi.so (the C-ABI declared in include/egomi.h).
+
+There is NO fallback: if the library is missing or a symbol is absent this module raises, and every
+op in egoscaler_amd.ops raises with it.  Nothing here imports oracle/.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libegomi.so")
+_lib = None
+
+c_p = ctypes.c_void_p
+c_i = ctypes.c_int
+c_d = ctypes.c_double
+c_f = ctypes.c_float
+c_sz = ctypes.c_size_t
+c_i64 = ctypes.c_int64
+
+
+class EgomiError(RuntimeError):
+    pass
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise EgomiError(f"{LIB_PATH} not found: build it with `python -m egoscaler_amd.build` "
+                             "(the product path has no CPU fallback)")
+        _lib = ctypes.CDLL(LIB_PATH)
+        _lib.egomi_strerror.restype = ctypes.c_char_p
+        _lib.egomi_strerror.argtypes = [c_i]
+        _lib.egomi_unproject_workspace_bytes.restype = c_sz
+        _lib.egomi_unproject_workspace_bytes.argtypes = [c_i] * 4
+    return _lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = lib().egomi_strerror(rc).decode()
+        raise EgomiError(f"{what}: egomi error {rc} ({msg})")
+
+
+def call(name: str, *args):
+    fn = getattr(lib(), name)
+    check(fn(*args), name)

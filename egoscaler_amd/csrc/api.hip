@@ -1,0 +1,15 @@
+// Library identity + error strings.
+#include "common.h"
+
+extern "C" int egomi_version(void) { return 100; }
+
+extern "C" const char* egomi_strerror(int code) {
+    switch (code) {
+        case EGOMI_OK: return "ok";
+        case EGOMI_E_BADARG: return "bad argument (null pointer, unknown dtype/enum)";
+        case EGOMI_E_SHAPE: return "shape/stride/workspace check failed";
+        case EGOMI_E_LAUNCH: return "HIP launch failed";
+        case EGOMI_E_UNSUPPORTED: return "size or mode not supported by this kernel";
+        default: return "unknown egomi error";
+    }
+}

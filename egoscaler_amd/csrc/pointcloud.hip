@@ -1,0 +1,475 @@
+// Point-cloud front end: RGB-D un-projection + ordered compaction (A1), pc_norm (A2), farthest
+// point sampling (A3), kNN grouping (A4+A5).  SURVEY.md §8a.  All HBM/latency-bound integer+fp32
+// work: no MFMA here.  This file is compiled with -ffp-contract=off: the index contracts (FPS and
+// kNN indices bit-exact with the reference's fp32 arithmetic) need un-fused mul/add.
+#include "common.h"
+#include <math.h>
+
+// =================================================================================================
+// A1  un-projection.  reference: data/tools/pcm_tools.py:68-96
+// three launches: (1) per-pixel validity -> 1 bit/pixel + per-chunk counts, (2) per-sample scan of
+// chunk counts, (3) ordered write of the selected valid pixels.  Pixel data is read once in (1)
+// (7 B/pixel) and only for the selected pixels in (3).
+// =================================================================================================
+#define UNP_ITEMS 8
+#define UNP_THREADS 256
+#define UNP_CHUNK (UNP_ITEMS * UNP_THREADS)
+
+struct UnpParams {
+    const uint8_t* rgb; const float* depth; const int32_t* boxes; int n_boxes;
+    int T, H, W; long long L;   // L = T*H*W pixels per sample
+    double pp, fx, fy; float d_thres; int use_thres;
+    int nchunks;
+};
+
+__device__ __forceinline__ bool unp_valid(const UnpParams& p, const uint8_t* rgb, const float* depth, long long i) {
+    const uint8_t* c = rgb + i * 3;
+    bool ok = (c[0] != 0) & (c[1] != 0) & (c[2] != 0);                // pcm_tools.py:79
+    if (p.use_thres) ok = ok && (depth[i] < p.d_thres);               // :87-89 (NaN depth -> false)
+    if (p.n_boxes > 0) {                                               // :80-85
+        const int hw = p.H * p.W;
+        const int r = (int)(i % hw);
+        const int v = r / p.W, u = r % p.W;
+        for (int k = 0; k < p.n_boxes; ++k) {
+            const int32_t* b = p.boxes + 4 * k;
+            if (v >= b[0] && v < b[1] && u >= b[2] && u < b[3]) ok = false;
+        }
+    }
+    return ok;
+}
+
+__global__ __launch_bounds__(UNP_THREADS) void unp_mask_kernel(UnpParams p, uint8_t* mask, int32_t* chunk_cnt) {
+    const int b = blockIdx.y, ch = blockIdx.x;
+    const uint8_t* rgb = p.rgb + (long long)b * p.L * 3;
+    const float* depth = p.depth + (long long)b * p.L;
+    const long long base = (long long)ch * UNP_CHUNK + (long long)threadIdx.x * UNP_ITEMS;
+    unsigned m = 0;
+    if (base + UNP_ITEMS <= p.L && p.n_boxes == 0) {
+        // fast path: 24 B of colour + 32 B of depth per thread, no box test
+        const uint8_t* c = rgb + base * 3;
+        uint8_t cb[24];
+        if ((((uintptr_t)c) & 7) == 0) {
+            const uint2* c8 = reinterpret_cast<const uint2*>(c);
+            uint2 a0 = c8[0], a1 = c8[1], a2 = c8[2];
+            uint32_t w[6] = {a0.x, a0.y, a1.x, a1.y, a2.x, a2.y};
+#pragma unroll
+            for (int k = 0; k < 24; ++k) cb[k] = (uint8_t)(w[k >> 2] >> (8 * (k & 3)));
+        } else {
+#pragma unroll
+            for (int k = 0; k < 24; ++k) cb[k] = c[k];
+        }
+        float z[UNP_ITEMS];
+        if ((((uintptr_t)(depth + base)) & 15) == 0) {
+            f32x4 z0 = *reinterpret_cast<const f32x4*>(depth + base);
+            f32x4 z1 = *reinterpret_cast<const f32x4*>(depth + base + 4);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { z[k] = z0[k]; z[4 + k] = z1[k]; }
+        } else {
+#pragma unroll
+            for (int k = 0; k < UNP_ITEMS; ++k) z[k] = depth[base + k];
+        }
+#pragma unroll
+        for (int k = 0; k < UNP_ITEMS; ++k) {
+            bool ok = (cb[3 * k] != 0) & (cb[3 * k + 1] != 0) & (cb[3 * k + 2] != 0);
+            if (p.use_thres) ok = ok && (z[k] < p.d_thres);
+            m |= (ok ? 1u : 0u) << k;
+        }
+    } else {
+        for (int k = 0; k < UNP_ITEMS; ++k) {
+            const long long i = base + k;
+            if (i < p.L && unp_valid(p, rgb, depth, i)) m |= 1u << k;
+        }
+    }
+    const long long mi = (long long)b * p.nchunks * UNP_THREADS + (long long)ch * UNP_THREADS + threadIdx.x;
+    mask[mi] = (uint8_t)m;
+    __shared__ float red[16];
+    // integer block sum via wave popcount adds
+    int cnt = __popc(m);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+    __shared__ int wsum[UNP_THREADS / 64];
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int t = 0;
+        for (int w = 0; w < UNP_THREADS / 64; ++w) t += wsum[w];
+        chunk_cnt[b * p.nchunks + ch] = t;
+    }
+    (void)red;
+}
+
+// one block per sample: exclusive scan of chunk counts (in place -> offsets), total -> out_count
+__global__ __launch_bounds__(1024) void unp_scan_kernel(int32_t* chunk_cnt, int nchunks, int n_out, int32_t* out_count) {
+    const int b = blockIdx.x;
+    int32_t* c = chunk_cnt + (long long)b * nchunks;
+    __shared__ int wtot[16];
+    __shared__ int carry_s;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (int base = 0; base < nchunks; base += 1024) {
+        const int i = base + threadIdx.x;
+        const int v = (i < nchunks) ? c[i] : 0;
+        int x = v;   // inclusive wave scan
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            int y = __shfl_up(x, o, 64);
+            if ((threadIdx.x & 63) >= o) x += y;
+        }
+        if ((threadIdx.x & 63) == 63) wtot[threadIdx.x >> 6] = x;
+        __syncthreads();
+        int woff = 0;
+        for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) woff += wtot[w];
+        const int carry = carry_s;
+        if (i < nchunks) c[i] = carry + woff + x - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry_s = carry + woff + x;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const int total = carry_s;
+        out_count[b] = (n_out > 0 && total < n_out) ? -total : total;
+    }
+}
+
+__global__ __launch_bounds__(UNP_THREADS) void unp_write_kernel(UnpParams p, const uint8_t* mask, const int32_t* chunk_off,
+                                                                const int32_t* out_count, int n_out, long long cap,
+                                                                double* out_points, float* out_colors) {
+    const int b = blockIdx.y, ch = blockIdx.x;
+    const int total = out_count[b];
+    if (total <= 0) return;                       // nothing valid, or too few for the subsample
+    const int stride = (n_out > 0) ? (total / n_out) : 1;
+    const int off = chunk_off[b * p.nchunks + ch];
+    const long long mi = (long long)b * p.nchunks * UNP_THREADS + (long long)ch * UNP_THREADS + threadIdx.x;
+    const unsigned m = mask[mi];
+    const int cnt = __popc(m);
+    int x = cnt;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        int y = __shfl_up(x, o, 64);
+        if ((threadIdx.x & 63) >= o) x += y;
+    }
+    __shared__ int wtot[UNP_THREADS / 64];
+    if ((threadIdx.x & 63) == 63) wtot[threadIdx.x >> 6] = x;
+    __syncthreads();
+    int woff = 0;
+    for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) woff += wtot[w];
+    int ord = off + woff + x - cnt;               // ordinal of this thread's first valid pixel
+    if (cnt == 0) return;
+    const uint8_t* rgb = p.rgb + (long long)b * p.L * 3;
+    const float* depth = p.depth + (long long)b * p.L;
+    const long long base = (long long)ch * UNP_CHUNK + (long long)threadIdx.x * UNP_ITEMS;
+    const int hw = p.H * p.W;
+    for (int k = 0; k < UNP_ITEMS; ++k) {
+        if (!((m >> k) & 1u)) continue;
+        const int o = ord++;
+        long long row;
+        if (n_out > 0) {
+            if (o % stride != 0) continue;
+            row = o / stride;
+            if (row >= n_out) continue;
+        } else {
+            row = o;
+        }
+        const long long i = base + k;
+        const int r = (int)(i % hw);
+        const int v = r / p.W, u = r % p.W;
+        const float zf = depth[i];
+        const double z = (double)zf;
+        const double xn = ((double)u - p.pp) / p.fx;          // pcm_tools.py:74
+        const double yn = ((double)v - p.pp) / p.fy;          // :75
+        double* op = out_points + ((long long)b * cap + row) * 3;
+        op[0] = xn * z;                                       // :77
+        op[1] = yn * z;
+        op[2] = z;
+        float* oc = out_colors + ((long long)b * cap + row) * 3;
+        const uint8_t* c = rgb + i * 3;
+        oc[0] = (float)c[0] / 255.0f;                         // :78 (float32 image / 255.0)
+        oc[1] = (float)c[1] / 255.0f;
+        oc[2] = (float)c[2] / 255.0f;
+    }
+}
+
+static inline int unp_nchunks(long long L) { return (int)((L + UNP_CHUNK - 1) / UNP_CHUNK); }
+
+extern "C" size_t egomi_unproject_workspace_bytes(int B, int T, int H, int W) {
+    if (B <= 0 || T <= 0 || H <= 0 || W <= 0) return 0;
+    const long long L = (long long)T * H * W;
+    const long long nch = unp_nchunks(L);
+    size_t mask_bytes = (size_t)B * nch * UNP_THREADS;
+    mask_bytes = (mask_bytes + 255) & ~(size_t)255;
+    return mask_bytes + (size_t)B * nch * sizeof(int32_t);
+}
+
+extern "C" int egomi_unproject_gather(const uint8_t* rgb, const float* depth, const int32_t* boxes, int n_boxes,
+                                      int B, int T, int H, int W, double pp, double fx, double fy, float d_thres,
+                                      int n_out, double* out_points, float* out_colors, int32_t* out_count,
+                                      void* workspace, size_t workspace_bytes, egomi_stream_t stream) {
+    if (!rgb || !depth || !out_points || !out_colors || !out_count || !workspace) return EGOMI_E_BADARG;
+    if (B <= 0 || T <= 0 || H <= 0 || W <= 0 || n_out < 0 || n_boxes < 0 || (n_boxes > 0 && !boxes)) return EGOMI_E_SHAPE;
+    if (fx == 0.0 || fy == 0.0) return EGOMI_E_BADARG;
+    const long long L = (long long)T * H * W;
+    if (L >= (1ll << 31)) return EGOMI_E_UNSUPPORTED;
+    if (workspace_bytes < egomi_unproject_workspace_bytes(B, T, H, W)) return EGOMI_E_SHAPE;
+    UnpParams p;
+    p.rgb = rgb; p.depth = depth; p.boxes = boxes; p.n_boxes = n_boxes;
+    p.T = T; p.H = H; p.W = W; p.L = L; p.pp = pp; p.fx = fx; p.fy = fy;
+    p.use_thres = !(d_thres != d_thres); p.d_thres = d_thres;
+    p.nchunks = unp_nchunks(L);
+    size_t mask_bytes = ((size_t)B * p.nchunks * UNP_THREADS + 255) & ~(size_t)255;
+    uint8_t* mask = (uint8_t*)workspace;
+    int32_t* cnt = (int32_t*)((char*)workspace + mask_bytes);
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid(p.nchunks, B);
+    hipLaunchKernelGGL(unp_mask_kernel, grid, dim3(UNP_THREADS), 0, s, p, mask, cnt);
+    hipLaunchKernelGGL(unp_scan_kernel, dim3(B), dim3(1024), 0, s, cnt, p.nchunks, n_out, out_count);
+    const long long cap = n_out > 0 ? n_out : L;
+    hipLaunchKernelGGL(unp_write_kernel, grid, dim3(UNP_THREADS), 0, s, p, mask, cnt, out_count, n_out, cap, out_points, out_colors);
+    return egomi_launch_status();
+}
+
+// =================================================================================================
+// A2  pc_norm.  reference: models/pointllm/pointllm/data/utils.py:146-157.  One block per sample.
+// =================================================================================================
+__device__ __forceinline__ double block_sum_f64(double v, double* red) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[w] = v;
+    __syncthreads();
+    double t = 0.0;
+    for (int i = 0; i < nw; ++i) t += red[i];
+    return t;
+}
+
+__global__ __launch_bounds__(1024) void pc_norm_kernel(const double* points, const float* colors, float* out, int N) {
+    const int b = blockIdx.x;
+    const double* P = points + (long long)b * N * 3;
+    const float* Cc = colors + (long long)b * N * 3;
+    float* O = out + (long long)b * N * 6;
+    __shared__ double red[16];
+    double sx = 0, sy = 0, sz = 0;
+    for (int i = threadIdx.x; i < N; i += blockDim.x) { sx += P[3 * i]; sy += P[3 * i + 1]; sz += P[3 * i + 2]; }
+    const double cx = block_sum_f64(sx, red) / (double)N;
+    const double cy = block_sum_f64(sy, red) / (double)N;
+    const double cz = block_sum_f64(sz, red) / (double)N;
+    double r2 = 0.0;
+    for (int i = threadIdx.x; i < N; i += blockDim.x) {
+        const double x = P[3 * i] - cx, y = P[3 * i + 1] - cy, z = P[3 * i + 2] - cz;
+        r2 = fmax(r2, (x * x + y * y) + z * z);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) r2 = fmax(r2, __shfl_xor(r2, o, 64));
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = r2;
+    __syncthreads();
+    double m2 = 0.0;
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) m2 = fmax(m2, red[i]);
+    const double m = sqrt(m2);                      // max(sqrt(.)) == sqrt(max(.)): sqrt is monotone
+    for (int i = threadIdx.x; i < N; i += blockDim.x) {
+        O[6 * i + 0] = (float)((P[3 * i] - cx) / m);
+        O[6 * i + 1] = (float)((P[3 * i + 1] - cy) / m);
+        O[6 * i + 2] = (float)((P[3 * i + 2] - cz) / m);
+        O[6 * i + 3] = Cc[3 * i];
+        O[6 * i + 4] = Cc[3 * i + 1];
+        O[6 * i + 5] = Cc[3 * i + 2];
+    }
+}
+
+extern "C" int egomi_pc_norm(const double* points, const float* colors, float* out, int B, int N, egomi_stream_t stream) {
+    if (!points || !colors || !out) return EGOMI_E_BADARG;
+    if (B <= 0 || N <= 0) return EGOMI_E_SHAPE;
+    hipLaunchKernelGGL(pc_norm_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, points, colors, out, N);
+    return egomi_launch_status();
+}
+
+// =================================================================================================
+// A3  farthest point sampling.  reference: pointbert/misc.py:40-60
+// One 1024-thread workgroup per cloud.  Each thread keeps PPT points and their running distances in
+// registers; the cloud's xyz is also staged in LDS (12 B/point) so the new centroid is one
+// broadcast LDS read.  Per iteration: PPT distance updates, a 64-bit (distance, ~index) arg-max by
+// wave shuffles, one barrier (double-buffered per-wave slots).
+// =================================================================================================
+#define FPS_THREADS 1024
+
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long k) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        unsigned lo = __shfl_xor((unsigned)(k & 0xFFFFFFFFu), o, 64);
+        unsigned hi = __shfl_xor((unsigned)(k >> 32), o, 64);
+        unsigned long long other = ((unsigned long long)hi << 32) | lo;
+        k = other > k ? other : k;
+    }
+    return k;
+}
+
+template <int PPT>
+__global__ __launch_bounds__(FPS_THREADS) void fps_kernel(const float* pts, int N, int C, const int32_t* start, int G,
+                                                          int32_t* out_idx, float* out_center) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    unsigned long long* slots = reinterpret_cast<unsigned long long*>(smem);   // [2][16]
+    float* lp = reinterpret_cast<float*>(smem + 2 * 16 * sizeof(unsigned long long));   // [N][3]
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float* P = pts + (long long)b * N * C;
+    float px[PPT], py[PPT], pz[PPT], dist[PPT];
+#pragma unroll
+    for (int s = 0; s < PPT; ++s) {
+        const int j = s * FPS_THREADS + tid;
+        if (j < N) {
+            px[s] = P[(long long)j * C]; py[s] = P[(long long)j * C + 1]; pz[s] = P[(long long)j * C + 2];
+            lp[3 * j] = px[s]; lp[3 * j + 1] = py[s]; lp[3 * j + 2] = pz[s];
+            dist[s] = 1e10f;                                               // misc.py:51
+        } else {
+            px[s] = py[s] = pz[s] = 0.f; dist[s] = -1.f;                   // padding: never selected
+        }
+    }
+    __syncthreads();
+    int far = start[b];
+    for (int i = 0; i < G; ++i) {
+        const float cx = lp[3 * far], cy = lp[3 * far + 1], cz = lp[3 * far + 2];
+        if (tid == 0) {
+            out_idx[(long long)b * G + i] = far;                           // misc.py:55
+            float* oc = out_center + ((long long)b * G + i) * 3;
+            oc[0] = cx; oc[1] = cy; oc[2] = cz;
+        }
+        unsigned long long best = 0ull;
+#pragma unroll
+        for (int s = 0; s < PPT; ++s) {
+            const float dx = px[s] - cx, dy = py[s] - cy, dz = pz[s] - cz;
+            const float d = (dx * dx + dy * dy) + dz * dz;                 // misc.py:57 (un-fused)
+            if (dist[s] >= 0.f) {
+                dist[s] = fminf(dist[s], d);                               // misc.py:58
+                const unsigned j = (unsigned)(s * FPS_THREADS + tid);
+                const unsigned long long key = ((unsigned long long)__float_as_uint(dist[s]) << 32) | (0xFFFFFFFFu - j);
+                best = key > best ? key : best;
+            }
+        }
+        best = wave_max_u64(best);
+        unsigned long long* sl = slots + (i & 1) * 16;
+        if ((tid & 63) == 0) sl[tid >> 6] = best;
+        __syncthreads();
+        unsigned long long k = sl[tid & 15];
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) {
+            unsigned lo = __shfl_xor((unsigned)(k & 0xFFFFFFFFu), o, 64);
+            unsigned hi = __shfl_xor((unsigned)(k >> 32), o, 64);
+            unsigned long long other = ((unsigned long long)hi << 32) | lo;
+            k = other > k ? other : k;
+        }
+        far = (int)(0xFFFFFFFFu - (unsigned)(k & 0xFFFFFFFFu));            // misc.py:59, lowest index on ties
+    }
+}
+
+extern "C" int egomi_fps(const float* pts, int B, int N, int C, const int32_t* start, int G,
+                         int32_t* out_idx, float* out_center, egomi_stream_t stream) {
+    if (!pts || !start || !out_idx || !out_center) return EGOMI_E_BADARG;
+    if (B <= 0 || N <= 0 || C < 3 || G <= 0) return EGOMI_E_SHAPE;
+    if (N > 16 * FPS_THREADS) return EGOMI_E_UNSUPPORTED;
+    const size_t lds = 2 * 16 * sizeof(unsigned long long) + (size_t)N * 3 * sizeof(float);
+    if (lds > 160 * 1024) return EGOMI_E_UNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    const int ppt = (N + FPS_THREADS - 1) / FPS_THREADS;
+#define FPS_LAUNCH(P)                                                                                       \
+    do {                                                                                                    \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fps_kernel<P>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL(fps_kernel<P>, dim3(B), dim3(FPS_THREADS), lds, s, pts, N, C, start, G, out_idx, out_center); \
+    } while (0)
+    if (ppt <= 1) FPS_LAUNCH(1);
+    else if (ppt <= 2) FPS_LAUNCH(2);
+    else if (ppt <= 4) FPS_LAUNCH(4);
+    else if (ppt <= 8) FPS_LAUNCH(8);
+    else FPS_LAUNCH(16);
+#undef FPS_LAUNCH
+    return egomi_launch_status();
+}
+
+// =================================================================================================
+// A4+A5  kNN grouping.  reference: pointbert/dvae.py:107-140,150-187
+// One wave per (cloud, centre).  Each lane holds CAND = 128 candidate distances in registers
+// (point j = slot*64 + lane); K rounds of {lane-local arg-min, 64-bit wave arg-min on
+// (orderable distance, index), invalidate}.  Rounds come out ordered by (distance, index).
+// =================================================================================================
+#define KNN_CAND 128
+#define KNN_WAVES 4
+
+__device__ __forceinline__ unsigned f32_orderable(float f) {
+    unsigned u = __float_as_uint(f);
+    return u ^ ((u >> 31) ? 0xFFFFFFFFu : 0x80000000u);
+}
+
+template <typename TO>
+__global__ __launch_bounds__(KNN_WAVES * 64) void knn_group_kernel(const float* pts, const float* center, int N, int C, int G, int K,
+                                                                  int total_groups, int32_t* out_idx, TO* out_nb) {
+    const int lane = threadIdx.x & 63;
+    const int gidx = blockIdx.x * KNN_WAVES + (threadIdx.x >> 6);        // b*G + g
+    if (gidx >= total_groups) return;                                   // whole wave exits together
+    const int b = gidx / G;
+    const float* P = pts + (long long)b * N * C;
+    const float cx = center[(long long)gidx * 3], cy = center[(long long)gidx * 3 + 1], cz = center[(long long)gidx * 3 + 2];
+    const float na = (cx * cx + cy * cy) + cz * cz;
+    float d[KNN_CAND];
+#pragma unroll
+    for (int s = 0; s < KNN_CAND; ++s) {
+        const int j = s * 64 + lane;
+        if (j < N) {
+            const float x = P[(long long)j * C], y = P[(long long)j * C + 1], z = P[(long long)j * C + 2];
+            const float dot = (cx * x + cy * y) + cz * z;
+            const float nb = (x * x + y * y) + z * z;
+            float t = -2.0f * dot;                                       // dvae.py:137
+            t = t + na;                                                  // dvae.py:138
+            t = t + nb;                                                  // dvae.py:139
+            d[s] = t;
+        } else {
+            d[s] = INFINITY;
+        }
+    }
+    int mine = 0;
+    int kill = -1;
+    for (int r = 0; r < K; ++r) {
+        unsigned bu = 0xFFFFFFFFu;
+        int bs = 0;
+#pragma unroll
+        for (int s = 0; s < KNN_CAND; ++s) {
+            if (s == kill) d[s] = INFINITY;
+            const unsigned u = f32_orderable(d[s]);
+            if (u < bu) { bu = u; bs = s; }
+        }
+        unsigned long long key = ((unsigned long long)bu << 32) | (unsigned)(bs * 64 + lane);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            unsigned lo = __shfl_xor((unsigned)(key & 0xFFFFFFFFu), o, 64);
+            unsigned hi = __shfl_xor((unsigned)(key >> 32), o, 64);
+            unsigned long long other = ((unsigned long long)hi << 32) | lo;
+            key = other < key ? other : key;
+        }
+        const int widx = (int)(key & 0xFFFFFFFFu);
+        kill = ((widx & 63) == lane) ? (widx >> 6) : -1;
+        if (lane == r) mine = widx;
+    }
+    if (lane < K) out_idx[(long long)gidx * K + lane] = mine;            // ordered by (distance, index)
+    const int tot = K * C;
+    for (int e = lane; e < tot; e += 64) {
+        const int r = e / C, c = e - r * C;
+        const int idx = __shfl(mine, r, 64);
+        float v = P[(long long)idx * C + c];
+        if (c == 0) v -= cx; else if (c == 1) v -= cy; else if (c == 2) v -= cz;   // dvae.py:182: xyz only
+        Cvt<TO>::st(out_nb + (long long)gidx * tot + e, v);
+    }
+}
+
+extern "C" int egomi_knn_group(const float* pts, const float* center, int B, int N, int C, int G, int K,
+                               int32_t* out_idx, void* out_nb, int out_dtype, egomi_stream_t stream) {
+    if (!pts || !center || !out_idx || !out_nb) return EGOMI_E_BADARG;
+    if (B <= 0 || N <= 0 || C < 3 || G <= 0 || K <= 0 || K > N) return EGOMI_E_SHAPE;
+    if (N > KNN_CAND * 64 || K > 64) return EGOMI_E_UNSUPPORTED;
+    const int total = B * G;
+    const int blocks = (total + KNN_WAVES - 1) / KNN_WAVES;
+    hipStream_t s = (hipStream_t)stream;
+    if (out_dtype == EGOMI_F32)
+        hipLaunchKernelGGL(knn_group_kernel<float>, dim3(blocks), dim3(KNN_WAVES * 64), 0, s, pts, center, N, C, G, K, total, out_idx, (float*)out_nb);
+    else if (out_dtype == EGOMI_BF16)
+        hipLaunchKernelGGL(knn_group_kernel<bf16_t>, dim3(blocks), dim3(KNN_WAVES * 64), 0, s, pts, center, N, C, G, K, total, out_idx, (bf16_t*)out_nb);
+    else
+        return EGOMI_E_BADARG;
+    return egomi_launch_status();
+}
