@@ -95,6 +95,12 @@ __device__ __forceinline__ float block_max(float v, float* red) {
     return t;
 }
 
+__device__ __forceinline__ float act_apply(float x, int act) {
+    if (act == 1) return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));   // exact (erf) GELU
+    if (act == 2) return fmaxf(x, 0.0f);
+    return x;
+}
+
 static inline int egomi_launch_status() {
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? EGOMI_OK : EGOMI_E_LAUNCH;

@@ -1,0 +1,700 @@
+// HBM-bound row/elementwise kernels of the path: LayerNorm, RMSNorm fwd/bwd, RoPE, SwiGLU, GELU,
+// softmax fwd/bwd (unfused attention), embedding gather + point-token splice fwd/bwd, cross-entropy
+// fwd+bwd, AdamW, transpose, cast, add, mini-PointNet group max, small-K linear.
+// All compute in fp32; I/O in T (float or bf16).  16-byte vector accesses where the shape allows.
+#include "common.h"
+#include <math.h>
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm forward (+ fused pre-add).  reference: point_encoder.py:60,63,74-75,95-98,142
+// one wave per row; x_sum = x + add is written when sum_out != NULL.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* x, const T* add, const T* w, const T* b, T* sum_out, T* y,
+                                                            int rows, int cols, float eps) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const T* xr = x + (long long)row * cols;
+    const T* ar = add ? add + (long long)row * cols : nullptr;
+    float s = 0.f;
+    for (int c = lane; c < cols; c += 64) {
+        float v = Cvt<T>::ld(xr + c);
+        if (ar) v += Cvt<T>::ld(ar + c);
+        s += v;
+    }
+    const float mean = wave_sum(s) / cols;
+    float q = 0.f;
+    for (int c = lane; c < cols; c += 64) {
+        float v = Cvt<T>::ld(xr + c);
+        if (ar) v += Cvt<T>::ld(ar + c);
+        if (sizeof(T) == 2) v = bf2f(f2bf(v));       // the sum is materialised in T by the reference
+        const float dlt = v - mean;
+        q += dlt * dlt;
+    }
+    const float rstd = rsqrtf(wave_sum(q) / cols + eps);
+    for (int c = lane; c < cols; c += 64) {
+        float v = Cvt<T>::ld(xr + c);
+        if (ar) v += Cvt<T>::ld(ar + c);
+        if (sum_out) Cvt<T>::st(sum_out + (long long)row * cols + c, v);
+        if (sizeof(T) == 2) v = bf2f(f2bf(v));
+        Cvt<T>::st(y + (long long)row * cols + c, (v - mean) * rstd * Cvt<T>::ld(w + c) + Cvt<T>::ld(b + c));
+    }
+}
+
+extern "C" int egomi_layernorm_fwd(const void* x, const void* add, const void* w, const void* b, void* sum_out, void* y,
+                                   int rows, int cols, float eps, int dtype, egomi_stream_t stream) {
+    if (!x || !w || !b || !y) return EGOMI_E_BADARG;
+    if (rows <= 0 || cols <= 0) return EGOMI_E_SHAPE;
+    EGOMI_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(layernorm_fwd_kernel<T>, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream,
+                                                   (const T*)x, (const T*)add, (const T*)w, (const T*)b, (T*)sum_out, (T*)y, rows, cols, eps));
+    return egomi_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------
+// RMSNorm.  reference: HF modeling_llama.py:53-67 (fp32 variance, x_hat cast back, then * weight)
+// one 256-thread block per row, 8-element vectors.  cols % 8 == 0.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const T* x, const T* w, T* y, float* rstd_out, int cols, float eps) {
+    __shared__ float red[16];
+    const long long row = blockIdx.x;
+    const T* xr = x + row * cols;
+    float s = 0.f;
+    for (int c = threadIdx.x * 8; c < cols; c += 256 * 8) {
+        float v[8];
+        load8<T>(xr + c, v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s += v[j] * v[j];
+    }
+    const float rstd = rsqrtf(block_sum(s, red) / cols + eps);
+    if (rstd_out && threadIdx.x == 0) rstd_out[row] = rstd;
+    for (int c = threadIdx.x * 8; c < cols; c += 256 * 8) {
+        float v[8], ww[8], o[8];
+        load8<T>(xr + c, v);
+        load8<T>(w + c, ww);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float h = v[j] * rstd;
+            if (sizeof(T) == 2) h = bf2f(f2bf(h));      // .to(input_dtype) before the weight multiply
+            o[j] = ww[j] * h;
+        }
+        store8<T>(y + row * cols + c, o);
+    }
+}
+
+// dx = rstd * (g - x_hat * mean(g * x_hat)),  g = w * dy;  dw[c] += sum_rows dy * x_hat.
+// grid = min(rows, 1024) blocks, each loops over rows; dw partials kept in registers, one atomic
+// per column per block at the end.
+template <typename T>
+__global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const T* dy, const T* x, const T* w, const float* rstd, T* dx, const T* dx_add,
+                                                          float* dw, int rows, int cols) {
+    __shared__ float red[16];
+    constexpr int MAXV = 4;                              // cols <= 256*8*4 = 8192
+    float dwp[MAXV][8];
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dwp[i][j] = 0.f;
+    for (long long row = blockIdx.x; row < rows; row += gridDim.x) {
+        const float rs = rstd[row];
+        float dot = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int c = (threadIdx.x + i * 256) * 8;
+            if (c < cols) {
+                float g[8], xv[8], ww[8];
+                load8<T>(dy + row * cols + c, g);
+                load8<T>(x + row * cols + c, xv);
+                load8<T>(w + c, ww);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) dot += g[j] * ww[j] * xv[j] * rs;
+            }
+        }
+        const float mean = block_sum(dot, red) / cols;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int c = (threadIdx.x + i * 256) * 8;
+            if (c < cols) {
+                float g[8], xv[8], ww[8], o[8], ad[8];
+                load8<T>(dy + row * cols + c, g);
+                load8<T>(x + row * cols + c, xv);
+                load8<T>(w + c, ww);
+                if (dx_add) load8<T>(dx_add + row * cols + c, ad);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float xh = xv[j] * rs;
+                    o[j] = rs * (g[j] * ww[j] - xh * mean) + (dx_add ? ad[j] : 0.f);
+                    dwp[i][j] += g[j] * xh;
+                }
+                store8<T>(dx + row * cols + c, o);
+            }
+        }
+    }
+    if (dw) {
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int c = (threadIdx.x + i * 256) * 8;
+            if (c < cols)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) atomicAdd(dw + c + j, dwp[i][j]);
+        }
+    }
+}
+
+extern "C" int egomi_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd, int rows, int cols, float eps, int dtype,
+                                 egomi_stream_t stream) {
+    if (!x || !w || !y) return EGOMI_E_BADARG;
+    if (rows <= 0 || cols <= 0 || cols % 8) return EGOMI_E_SHAPE;
+    EGOMI_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(rmsnorm_fwd_kernel<T>, dim3(rows), dim3(256), 0, (hipStream_t)stream,
+                                                   (const T*)x, (const T*)w, (T*)y, rstd, cols, eps));
+    return egomi_launch_status();
+}
+
+extern "C" int egomi_rmsnorm_bwd(const void* dy, const void* x, const void* w, const float* rstd, void* dx, const void* dx_add,
+                                 float* dw, int rows, int cols, int dtype, egomi_stream_t stream) {
+    if (!dy || !x || !w || !rstd || !dx) return EGOMI_E_BADARG;
+    if (rows <= 0 || cols <= 0 || cols % 8) return EGOMI_E_SHAPE;
+    if (cols > 8192) return EGOMI_E_UNSUPPORTED;
+    const int grid = rows < 1024 ? rows : 1024;
+    EGOMI_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(rmsnorm_bwd_kernel<T>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                                                   (const T*)dy, (const T*)x, (const T*)w, rstd, (T*)dx, (const T*)dx_add, dw, rows, cols));
+    return egomi_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------
+// RoPE in place on [rows, H, hd] with row stride ld.  reference: HF modeling_llama.py:112-160
+// (half-split rotate_half; cos/sin are fp32 tables cast to the activation dtype, products and the
+// sum each rounded in that dtype).  inverse=1 applies the transpose rotation (backward).
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void rope_kernel(T* x, const float* cos_tab, const float* sin_tab, long long rows, int S, int pos_offset,
+                                                   int H, int hd, long long ld, int inverse) {
+    const int half = hd >> 1;
+    const long long total = rows * H * half;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const int i = (int)(e % half);
+        const int h = (int)((e / half) % H);
+        const long long r = e / ((long long)half * H);
+        const int pos = pos_offset + (int)(r % S);
+        float c = cos_tab[(long long)pos * half + i], s = sin_tab[(long long)pos * half + i];
+        if (inverse) s = -s;
+        T* p = x + r * ld + (long long)h * hd + i;
+        const float a = Cvt<T>::ld(p), b = Cvt<T>::ld(p + half);
+        float oa, ob;
+        if (sizeof(T) == 2) {
+            c = bf2f(f2bf(c)); s = bf2f(f2bf(s));
+            oa = bf2f(f2bf(a * c)) + bf2f(f2bf(-b * s));
+            ob = bf2f(f2bf(b * c)) + bf2f(f2bf(a * s));
+        } else {
+            oa = a * c + (-b) * s;
+            ob = b * c + a * s;
+        }
+        Cvt<T>::st(p, oa);
+        Cvt<T>::st(p + half, ob);
+    }
+}
+
+extern "C" int egomi_rope(void* x, const float* cos_tab, const float* sin_tab, int64_t rows, int S, int pos_offset, int H, int hd,
+                          int64_t ld, int inverse, int dtype, egomi_stream_t stream) {
+    if (!x || !cos_tab || !sin_tab) return EGOMI_E_BADARG;
+    if (rows <= 0 || S <= 0 || H <= 0 || hd <= 0 || (hd & 1) || ld < (int64_t)H * hd || pos_offset < 0) return EGOMI_E_SHAPE;
+    const long long total = rows * H * (hd / 2);
+    const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    EGOMI_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(rope_kernel<T>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                                                   (T*)x, cos_tab, sin_tab, rows, S, pos_offset, H, hd, ld, inverse));
+    return egomi_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------
+// SwiGLU.  reference: HF modeling_llama.py:174-176  down(silu(gate(x)) * up(x))
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+
+template <typename T>
+__global__ __launch_bounds__(256) void swiglu_fwd_kernel(const T* gate, const T* up, T* out, long long rows, int cols, long long ld_in, long long ld_out) {
+    const int cv = cols / 8;
+    const long long total = rows * cv;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const long long r = e / cv;
+        const int c = (int)(e % cv) * 8;
+        float g[8], u[8], o[8];
+        load8<T>(gate + r * ld_in + c, g);
+        load8<T>(up + r * ld_in + c, u);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float a = g[j] * sigmoidf_(g[j]);
+            if (sizeof(T) == 2) a = bf2f(f2bf(a));
+            o[j] = a * u[j];
+        }
+        store8<T>(out + r * ld_out + c, o);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void swiglu_bwd_kernel(const T* dact, const T* gate, const T* up, T* dgate, T* dup, long long rows, int cols,
+                                                         long long ld_in, long long ld_act, long long ld_out) {
+    const int cv = cols / 8;
+    const long long total = rows * cv;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const long long r = e / cv;
+        const int c = (int)(e % cv) * 8;
+        float d[8], g[8], u[8], og[8], ou[8];
+        load8<T>(dact + r * ld_act + c, d);
+        load8<T>(gate + r * ld_in + c, g);
+        load8<T>(up + r * ld_in + c, u);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float sg = sigmoidf_(g[j]);
+            ou[j] = d[j] * g[j] * sg;
+            og[j] = d[j] * u[j] * sg * (1.0f + g[j] * (1.0f - sg));
+        }
+        store8<T>(dgate + r * ld_out + c, og);
+        store8<T>(dup + r * ld_out + c, ou);
+    }
+}
+
+static inline int ew_grid(long long total) { long long g = (total + 255) / 256; return (int)(g < 1 ? 1 : (g > 16384 ? 16384 : g)); }
+
+extern "C" int egomi_swiglu_fwd(const void* gate, const void* up, void* out, int64_t rows, int cols, int64_t ld_in, int64_t ld_out,
+                                int dtype, egomi_stream_t stream) {
+    if (!gate || !up || !out) return EGOMI_E_BADARG;
+    if (rows <= 0 || cols <= 0 || cols % 8 || ld_in % 8 || ld_out % 8 || ld_in < cols || ld_out < cols) return EGOMI_E_SHAPE;
+    EGOMI_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(swiglu_fwd_kernel<T>, dim3(ew_grid(rows * (cols / 8))), dim3(256), 0, (hipStream_t)stream,
+                                                   (const T*)gate, (const T*)up, (T*)out, rows, cols, ld_in, ld_out));
+    return egomi_launch_status();
+}
+
+extern "C" int egomi_swiglu_bwd(const void* dact, const void* gate, const void* up, void* dgate, void* dup, int64_t rows, int cols,
+                                int64_t ld_in, int64_t ld_act, int64_t ld_out, int dtype, egomi_stream_t stream) {
+    if (!dact || !gate || !up || !dgate || !dup) return EGOMI_E_BADARG;
+    if (rows <= 0 || cols <= 0 || cols % 8 || ld_in % 8 || ld_act % 8 || ld_out % 8) return EGOMI_E_SHAPE;
+    EGOMI_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(swiglu_bwd_kernel<T>, dim3(ew_grid(rows * (cols / 8))), dim3(256), 0, (hipStream_t)stream,
+                                                   (const T*)dact, (const T*)gate, (const T*)up, (T*)dgate, (T*)dup, rows, cols, ld_in, ld_act, ld_out));
+    return egomi_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------
+// GELU (erf) forward / backward on flat arrays.  reference: nn.GELU() in point_proj, pointllm.py:72-76
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void gelu_kernel(const T* x, const T* dy, T* out, long long n) {
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long long)gridDim.x * 256) {
+        const float v = Cvt<T>::ld(x + e);
+        const float cdf = 0.5f * (1.0f + erff(v * 0.70710678118654752440f));
+        if (dy) {
+            const float pdf = 0.3989422804014327f * __expf(-0.5f * v * v);
+            Cvt<T>::st(out + e, Cvt<T>::ld(dy + e) * (cdf + v * pdf));
+        } else {
+            Cvt<T>::st(out + e, v * cdf);
+        }
+    }
+}
+extern "C" int egomi_gelu_fwd(const void* x, void* y, int64_t n, int dtype, egomi_stream_t stream) {
+    if (!x || !y) return EGOMI_E_BADARG;
+    if (n <= 0) return EGOMI_E_SHAPE;
+    EGOMI_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(gelu_kernel<T>, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, (const T*)x, (const T*)nullptr, (T*)y, n));
+    return egomi_launch_status();
+}
+extern "C" int egomi_gelu_bwd(const void* dy, const void* x, void* dx, int64_t n, int dtype, egomi_stream_t stream) {
+    if (!x || !dy || !dx) return EGOMI_E_BADARG;
+    if (n <= 0) return EGOMI_E_SHAPE;
+    EGOMI_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(gelu_kernel<T>, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, (const T*)x, (const T*)dy, (T*)dx, n));
+    return egomi_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Row softmax over fp32 scores (unfused attention path).  reference: point_encoder.py:48-50 and
+// HF modeling_llama.py:204-210 (scores + causal/padding mask, softmax in fp32, cast).
+// one wave per row, Sk <= 2048.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_fwd_kernel(const float* sc, const uint8_t* key_mask, long long rows, int heads, int Sq, int Sk,
+                                                          long long ld_s, int causal, int q_offset, T* P, long long ld_p) {
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const int qi = (int)(row % Sq);
+    const long long z = row / Sq;
+    const int b = (int)(z / heads);
+    const float* s = sc + row * ld_s;
+    const uint8_t* km = key_mask ? key_mask + (long long)b * Sk : nullptr;
+    const int lim = causal ? (q_offset + qi) : (Sk - 1);      // keys j <= lim are visible
+    constexpr int MAXE = 32;
+    float v[MAXE];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < MAXE; ++i) {
+        const int j = lane + i * 64;
+        float x = -INFINITY;
+        if (j < Sk && j <= lim && (!km || km[j])) x = s[j];
+        v[i] = x;
+        mx = fmaxf(mx, x);
+    }
+    mx = wave_max(mx);
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXE; ++i) {
+        const float e = (v[i] == -INFINITY) ? 0.f : __expf(v[i] - mx);
+        v[i] = e;
+        sum += e;
+    }
+    sum = wave_sum(sum);
+    const float inv = sum > 0.f ? 1.0f / sum : 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXE; ++i) {
+        const int j = lane + i * 64;
+        if (j < Sk) Cvt<T>::st(P + row * ld_p + j, v[i] * inv);
+    }
+}
+
+// dS = P * (dP - sum_j P*dP)
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_bwd_kernel(const T* P, long long ld_p, const float* dP, long long ld_dp, T* dS, long long ld_ds,
+                                                          long long rows, int Sk) {
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    float dot = 0.f;
+    for (int j = lane; j < Sk; j += 64) dot += Cvt<T>::ld(P + row * ld_p + j) * dP[row * ld_dp + j];
+    dot = wave_sum(dot);
+    for (int j = lane; j < Sk; j += 64) {
+        const float p = Cvt<T>::ld(P + row * ld_p + j);
+        Cvt<T>::st(dS + row * ld_ds + j, p * (dP[row * ld_dp + j] - dot));
+    }
+}
+
+extern "C" int egomi_softmax_fwd(const float* scores, int64_t ld_s, const uint8_t* key_mask, int Z, int heads, int Sq, int Sk, int causal,
+                                 int q_offset, void* P, int64_t ld_p, int dtype, egomi_stream_t stream) {
+    if (!scores || !P) return EGOMI_E_BADARG;
+    if (Z <= 0 || heads <= 0 || Sq <= 0 || Sk <= 0 || ld_s < Sk || ld_p < Sk) return EGOMI_E_SHAPE;
+    if (Sk > 2048) return EGOMI_E_UNSUPPORTED;
+    const long long rows = (long long)Z * Sq;
+    EGOMI_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(softmax_fwd_kernel<T>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                                                   scores, key_mask, rows, heads, Sq, Sk, ld_s, causal, q_offset, (T*)P, ld_p));
+    return egomi_launch_status();
+}
+
+extern "C" int egomi_softmax_bwd(const void* P, int64_t ld_p, const float* dP, int64_t ld_dp, void* dS, int64_t ld_ds, int64_t rows, int Sk,
+                                 int dtype, egomi_stream_t stream) {
+    if (!P || !dP || !dS) return EGOMI_E_BADARG;
+    if (rows <= 0 || Sk <= 0) return EGOMI_E_SHAPE;
+    EGOMI_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(softmax_bwd_kernel<T>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                                                   (const T*)P, ld_p, dP, ld_dp, (T*)dS, ld_ds, rows, Sk));
+    return egomi_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------
+// A10  point-token splice.  reference: model/pointllm.py:131-171 (mm_use_point_start_end = True)
+// splice_scan: integer position logic (one block per sample).  err: 0 ok, 1 start/end count
+// mismatch (:146), 2 end token not at start+P+1 (:150), 3 more than one point segment in a sample
+// (the reference consumes consecutive clouds; this build supports one cloud per sample).
+// start_pos = -1 for a text-only sample (:137-142).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void splice_scan_kernel(const int64_t* ids, int S, int64_t patch_id, int64_t start_id, int64_t end_id, int P,
+                                                          int32_t* start_pos, int32_t* err) {
+    const int b = blockIdx.x;
+    const int64_t* r = ids + (long long)b * S;
+    __shared__ int n_patch, n_start, n_end, first_start;
+    if (threadIdx.x == 0) { n_patch = 0; n_start = 0; n_end = 0; first_start = 0x7FFFFFFF; }
+    __syncthreads();
+    for (int s = threadIdx.x; s < S; s += 256) {
+        const int64_t t = r[s];
+        if (t == patch_id) atomicAdd(&n_patch, 1);
+        if (t == start_id) { atomicAdd(&n_start, 1); atomicMin(&first_start, s); }
+        if (t == end_id) atomicAdd(&n_end, 1);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int e = 0, sp = -1;
+        if (n_patch > 0) {
+            if (n_start != n_end) e = 1;
+            else if (n_start > 1) e = 3;
+            else if (n_start == 1) {
+                sp = first_start;
+                if (sp + P + 1 >= S || r[sp + P + 1] != end_id) e = 2;
+            }
+        }
+        start_pos[b] = e ? -1 : sp;
+        err[b] = e;
+    }
+}
+
+extern "C" int egomi_splice_scan(const int64_t* ids, int B, int S, int64_t patch_id, int64_t start_id, int64_t end_id, int P,
+                                 int32_t* start_pos, int32_t* err, egomi_stream_t stream) {
+    if (!ids || !start_pos || !err) return EGOMI_E_BADARG;
+    if (B <= 0 || S <= 0 || P <= 0) return EGOMI_E_SHAPE;
+    hipLaunchKernelGGL(splice_scan_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, ids, S, patch_id, start_id, end_id, P, start_pos, err);
+    return egomi_launch_status();
+}
+
+// out[b,s,:] = feats[b, s-start-1, :] if start < s <= start+P else W[ids[b,s], :]   (pointllm.py:107,155)
+template <typename T>
+__global__ __launch_bounds__(256) void embed_splice_fwd_kernel(const int64_t* ids, const T* W, const T* feats, const int32_t* start_pos,
+                                                               int S, int d, int P, int V, T* out) {
+    const long long row = blockIdx.x;
+    const int b = (int)(row / S), s = (int)(row % S);
+    const int sp = (feats && start_pos) ? start_pos[b] : -1;
+    const T* src;
+    if (sp >= 0 && s > sp && s <= sp + P) src = feats + ((long long)b * P + (s - sp - 1)) * d;
+    else {
+        long long t = ids[row];
+        if (t < 0 || t >= V) t = 0;                         // guarded on the host too
+        src = W + t * d;
+    }
+    for (int c = threadIdx.x * 8; c < d; c += 256 * 8) {
+        float v[8];
+        load8<T>(src + c, v);
+        store8<T>(out + row * d + c, v);
+    }
+}
+
+// dW[ids] += dout (fp32 atomics, rows outside the point span); dfeats = dout rows inside the span
+template <typename T>
+__global__ __launch_bounds__(256) void embed_splice_bwd_kernel(const T* dout, const int64_t* ids, const int32_t* start_pos, int S, int d, int P,
+                                                               int V, float* dW, T* dfeats) {
+    const long long row = blockIdx.x;
+    const int b = (int)(row / S), s = (int)(row % S);
+    const int sp = start_pos ? start_pos[b] : -1;
+    const bool in_span = sp >= 0 && s > sp && s <= sp + P;
+    if (in_span) {
+        if (!dfeats) return;
+        T* dst = dfeats + ((long long)b * P + (s - sp - 1)) * d;
+        for (int c = threadIdx.x * 8; c < d; c += 256 * 8) {
+            float v[8];
+            load8<T>(dout + row * d + c, v);
+            store8<T>(dst + c, v);
+        }
+    } else if (dW) {
+        const long long t = ids[row];
+        if (t < 0 || t >= V) return;
+        for (int c = threadIdx.x; c < d; c += 256) atomicAdd(dW + t * d + c, Cvt<T>::ld(dout + row * d + c));
+    }
+}
+
+extern "C" int egomi_embed_splice_fwd(const int64_t* ids, const void* W, const void* feats, const int32_t* start_pos, int B, int S, int d,
+                                      int P, int V, void* out, int dtype, egomi_stream_t stream) {
+    if (!ids || !W || !out) return EGOMI_E_BADARG;
+    if (B <= 0 || S <= 0 || d <= 0 || d % 8 || V <= 0) return EGOMI_E_SHAPE;
+    EGOMI_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(embed_splice_fwd_kernel<T>, dim3(B * S), dim3(256), 0, (hipStream_t)stream,
+                                                   ids, (const T*)W, (const T*)feats, start_pos, S, d, P, V, (T*)out));
+    return egomi_launch_status();
+}
+
+extern "C" int egomi_embed_splice_bwd(const void* dout, const int64_t* ids, const int32_t* start_pos, int B, int S, int d, int P, int V,
+                                      float* dW, void* dfeats, int dtype, egomi_stream_t stream) {
+    if (!dout || !ids) return EGOMI_E_BADARG;
+    if (B <= 0 || S <= 0 || d <= 0 || d % 8 || V <= 0) return EGOMI_E_SHAPE;
+    EGOMI_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(embed_splice_bwd_kernel<T>, dim3(B * S), dim3(256), 0, (hipStream_t)stream,
+                                                   (const T*)dout, ids, start_pos, S, d, P, V, dW, (T*)dfeats));
+    return egomi_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------
+// A12  cross-entropy over the trajectory span.  reference: train.py:174-181
+// F.cross_entropy(logits, targets, ignore_index=pad): mean over non-ignored rows.
+// ce_count counts them; ce_fwd_bwd adds -log p[target] into loss_sum (fp32 atomics) and writes
+// dlogits = (softmax - onehot) * grad_scale / count  (zero rows for ignored targets).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ce_count_kernel(const int64_t* tg, long long n, int64_t ignore, int32_t* count) {
+    int c = 0;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) c += (tg[i] != ignore);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(count, c);
+}
+
+template <typename T>
+__global__ __launch_bounds__(1024) void ce_fwd_bwd_kernel(const T* logits, long long ld, const int64_t* tg, int V, int64_t ignore,
+                                                          const int32_t* count, float* loss_sum, T* dlogits, long long ldd, float grad_scale) {
+    __shared__ float red[16];
+    const long long row = blockIdx.x;
+    const T* lr = logits + row * ld;
+    const int64_t t = tg[row];
+    const bool ign = (t == ignore) || t < 0 || t >= V;
+    if (ign) {
+        if (dlogits) for (int c = threadIdx.x; c < V; c += 1024) Cvt<T>::st(dlogits + row * ldd + c, 0.f);
+        return;
+    }
+    float mx = -INFINITY;
+    for (int c = threadIdx.x; c < V; c += 1024) mx = fmaxf(mx, Cvt<T>::ld(lr + c));
+    mx = block_max(mx, red);
+    float s = 0.f;
+    for (int c = threadIdx.x; c < V; c += 1024) s += __expf(Cvt<T>::ld(lr + c) - mx);
+    s = block_sum(s, red);
+    const float lse = mx + __logf(s);
+    if (threadIdx.x == 0) atomicAdd(loss_sum, lse - Cvt<T>::ld(lr + t));
+    if (dlogits) {
+        const float sc = grad_scale / (float)(*count);
+        for (int c = threadIdx.x; c < V; c += 1024) {
+            float p = __expf(Cvt<T>::ld(lr + c) - lse);
+            if (c == t) p -= 1.0f;
+            Cvt<T>::st(dlogits + row * ldd + c, p * sc);
+        }
+    }
+}
+
+extern "C" int egomi_ce_count(const int64_t* targets, int64_t n, int64_t ignore, int32_t* count, egomi_stream_t stream) {
+    if (!targets || !count) return EGOMI_E_BADARG;
+    if (n <= 0) return EGOMI_E_SHAPE;
+    hipLaunchKernelGGL(ce_count_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, targets, n, ignore, count);
+    return egomi_launch_status();
+}
+
+extern "C" int egomi_ce_fwd_bwd(const void* logits, int64_t ld, const int64_t* targets, int R, int V, int64_t ignore, const int32_t* count,
+                                float* loss_sum, void* dlogits, int64_t ldd, float grad_scale, int dtype, egomi_stream_t stream) {
+    if (!logits || !targets || !count || !loss_sum) return EGOMI_E_BADARG;
+    if (R <= 0 || V <= 0 || ld < V || (dlogits && ldd < V)) return EGOMI_E_SHAPE;
+    EGOMI_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(ce_fwd_bwd_kernel<T>, dim3(R), dim3(1024), 0, (hipStream_t)stream,
+                                                   (const T*)logits, ld, targets, V, ignore, count, loss_sum, (T*)dlogits, ldd, grad_scale));
+    return egomi_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------
+// AdamW (torch.optim.AdamW semantics, reference optimizer: train.py:107-111).  fp32 master/moments;
+// optional low-precision model copy written in the same pass.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void adamw_kernel(float* p, T* p_model, const float* g, float* m, float* v, long long n, float lr, float b1,
+                                                    float b2, float eps, float wd, float bc1, float bc2_sqrt, float gscale) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const float gr = g[i] * gscale;
+        float pi = p[i] * (1.0f - lr * wd);
+        const float mi = b1 * m[i] + (1.0f - b1) * gr;
+        const float vi = b2 * v[i] + (1.0f - b2) * gr * gr;
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        pi -= (lr / bc1) * (mi / denom);
+        p[i] = pi; m[i] = mi; v[i] = vi;
+        if (p_model) Cvt<T>::st(p_model + i, pi);
+    }
+}
+
+extern "C" int egomi_adamw(float* master, void* model_copy, const float* grad, float* m, float* v, int64_t n, float lr, float beta1,
+                           float beta2, float eps, float weight_decay, int step, float grad_scale, int copy_dtype, egomi_stream_t stream) {
+    if (!master || !grad || !m || !v) return EGOMI_E_BADARG;
+    if (n <= 0 || step <= 0) return EGOMI_E_SHAPE;
+    const float bc1 = 1.0f - powf(beta1, (float)step), bc2s = sqrtf(1.0f - powf(beta2, (float)step));
+    if (!model_copy || copy_dtype == EGOMI_F32)
+        hipLaunchKernelGGL(adamw_kernel<float>, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, master, (float*)model_copy, grad, m, v,
+                           (long long)n, lr, beta1, beta2, eps, weight_decay, bc1, bc2s, grad_scale);
+    else if (copy_dtype == EGOMI_BF16)
+        hipLaunchKernelGGL(adamw_kernel<bf16_t>, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, master, (bf16_t*)model_copy, grad, m, v,
+                           (long long)n, lr, beta1, beta2, eps, weight_decay, bc1, bc2s, grad_scale);
+    else return EGOMI_E_BADARG;
+    return egomi_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------
+// transpose [R,C] (ldi) -> [C, ldo] with columns R..ldo-1 zero-filled (32x32 LDS tiles); cast; add
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_kernel(const T* in, int R, int C, long long ldi, T* out, long long ldo) {
+    __shared__ T tile[32][33];
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;    // 32 x 8
+    for (int i = ty; i < 32; i += 8) {
+        const int r = r0 + i, c = c0 + tx;
+        tile[i][tx] = (r < R && c < C) ? in[(long long)r * ldi + c] : (T)0;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        const int c = c0 + i, r = r0 + tx;
+        if (c < C && r < ldo) out[(long long)c * ldo + r] = tile[tx][i];
+    }
+}
+
+extern "C" int egomi_transpose(const void* in, int R, int C, int64_t ldi, void* out, int64_t ldo, int dtype, egomi_stream_t stream) {
+    if (!in || !out) return EGOMI_E_BADARG;
+    if (R <= 0 || C <= 0 || ldi < C || ldo < R) return EGOMI_E_SHAPE;
+    dim3 grid((C + 31) / 32, (unsigned)((ldo + 31) / 32));
+    EGOMI_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(transpose_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, (const T*)in, R, C, ldi, (T*)out, ldo));
+    return egomi_launch_status();
+}
+
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void cast_kernel(const TI* in, TO* out, long long n) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) Cvt<TO>::st(out + i, Cvt<TI>::ld(in + i));
+}
+extern "C" int egomi_cast(const void* in, int in_dtype, void* out, int out_dtype, int64_t n, egomi_stream_t stream) {
+    if (!in || !out) return EGOMI_E_BADARG;
+    if (n <= 0) return EGOMI_E_SHAPE;
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 g(ew_grid(n)), b(256);
+    if (in_dtype == EGOMI_F32 && out_dtype == EGOMI_BF16) hipLaunchKernelGGL((cast_kernel<float, bf16_t>), g, b, 0, s, (const float*)in, (bf16_t*)out, (long long)n);
+    else if (in_dtype == EGOMI_BF16 && out_dtype == EGOMI_F32) hipLaunchKernelGGL((cast_kernel<bf16_t, float>), g, b, 0, s, (const bf16_t*)in, (float*)out, (long long)n);
+    else if (in_dtype == EGOMI_F32 && out_dtype == EGOMI_F32) hipLaunchKernelGGL((cast_kernel<float, float>), g, b, 0, s, (const float*)in, (float*)out, (long long)n);
+    else if (in_dtype == EGOMI_BF16 && out_dtype == EGOMI_BF16) hipLaunchKernelGGL((cast_kernel<bf16_t, bf16_t>), g, b, 0, s, (const bf16_t*)in, (bf16_t*)out, (long long)n);
+    else return EGOMI_E_BADARG;
+    return egomi_launch_status();
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void add_kernel(const T* a, const T* b, T* out, long long n) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+        Cvt<T>::st(out + i, Cvt<T>::ld(a + i) + Cvt<T>::ld(b + i));
+}
+extern "C" int egomi_add(const void* a, const void* b, void* out, int64_t n, int dtype, egomi_stream_t stream) {
+    if (!a || !b || !out) return EGOMI_E_BADARG;
+    if (n <= 0) return EGOMI_E_SHAPE;
+    EGOMI_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(add_kernel<T>, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, (const T*)a, (const T*)b, (T*)out, (long long)n));
+    return egomi_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------
+// A6 helpers (mini-PointNet, reference: pointbert/dvae.py:207-221)
+// group_max: [BG, M, C] -> [BG, C];  concat=1: out [BG*M, 2C] = [max over the group | x]  (:216-217)
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void group_max_kernel(const T* x, int M, int C, T* out, int concat) {
+    const long long g = blockIdx.x;
+    const T* xg = x + g * M * C;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float mx = -INFINITY;
+        for (int m = 0; m < M; ++m) mx = fmaxf(mx, Cvt<T>::ld(xg + (long long)m * C + c));
+        if (!concat) {
+            Cvt<T>::st(out + g * C + c, mx);
+        } else {
+            for (int m = 0; m < M; ++m) {
+                T* o = out + (g * M + m) * 2 * C;
+                Cvt<T>::st(o + c, mx);
+                o[C + c] = xg[(long long)m * C + c];
+            }
+        }
+    }
+}
+extern "C" int egomi_group_max(const void* x, int BG, int M, int C, void* out, int concat, int dtype, egomi_stream_t stream) {
+    if (!x || !out) return EGOMI_E_BADARG;
+    if (BG <= 0 || M <= 0 || C <= 0) return EGOMI_E_SHAPE;
+    EGOMI_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(group_max_kernel<T>, dim3(BG), dim3(256), 0, (hipStream_t)stream, (const T*)x, M, C, (T*)out, concat));
+    return egomi_launch_status();
+}
+
+// y[r,n] = act(sum_k x[r,k] * w[n,k] + b[n]) for K <= 8 (pos_embed.0: K=3, point_encoder.py:128;
+// first 1x1 conv: K=6, dvae.py:194).  x may be fp32 while y/w/b are T.
+template <typename TX, typename T>
+__global__ __launch_bounds__(256) void linear_smallk_kernel(const TX* x, const T* w, const T* b, T* y, long long R, int N, int K, int act) {
+    const long long total = R * N;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const long long r = e / N;
+        const int n = (int)(e % N);
+        float acc = 0.f;
+        for (int k = 0; k < K; ++k) acc = fmaf(Cvt<TX>::ld(x + r * K + k), Cvt<T>::ld(w + (long long)n * K + k), acc);
+        acc += b ? Cvt<T>::ld(b + n) : 0.f;
+        Cvt<T>::st(y + e, act_apply(acc, act));
+    }
+}
+
+extern "C" int egomi_linear_smallk(const void* x, int x_dtype, const void* w, const void* b, void* y, int64_t R, int N, int K, int act,
+                                   int dtype, egomi_stream_t stream) {
+    if (!x || !w || !y) return EGOMI_E_BADARG;
+    if (R <= 0 || N <= 0 || K <= 0 || K > 8 || act < 0 || act > 2) return EGOMI_E_SHAPE;
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 g(ew_grid(R * N)), bl(256);
+    if (x_dtype == EGOMI_F32 && dtype == EGOMI_F32)
+        hipLaunchKernelGGL((linear_smallk_kernel<float, float>), g, bl, 0, s, (const float*)x, (const float*)w, (const float*)b, (float*)y, (long long)R, N, K, act);
+    else if (x_dtype == EGOMI_F32 && dtype == EGOMI_BF16)
+        hipLaunchKernelGGL((linear_smallk_kernel<float, bf16_t>), g, bl, 0, s, (const float*)x, (const bf16_t*)w, (const bf16_t*)b, (bf16_t*)y, (long long)R, N, K, act);
+    else if (x_dtype == EGOMI_BF16 && dtype == EGOMI_BF16)
+        hipLaunchKernelGGL((linear_smallk_kernel<bf16_t, bf16_t>), g, bl, 0, s, (const bf16_t*)x, (const bf16_t*)w, (const bf16_t*)b, (bf16_t*)y, (long long)R, N, K, act);
+    else return EGOMI_E_BADARG;
+    return egomi_launch_status();
+}

@@ -90,3 +90,206 @@ def knn_group(pts, center, k, out_dtype=torch.float32):
     nb = torch.empty(B, G, k, C, dtype=out_dtype, device=pts.device)
     call("egomi_knn_group", P(pts), P(center), c_i(B), c_i(N), c_i(C), c_i(G), c_i(k), P(idx), P(nb), c_i(dt(out_dtype)), S())
     return idx, nb
+
+
+# ------------------------------------------------------------------------------------------ GEMM
+class GemmDesc(ctypes.Structure):
+    _fields_ = [("A", c_p), ("B", c_p), ("C", c_p), ("bias", c_p), ("residual", c_p),
+                ("M", c_i), ("N", c_i), ("K", c_i),
+                ("lda", c_i64), ("ldb", c_i64), ("ldc", c_i64), ("ldr", c_i64),
+                ("a_layout", c_i), ("b_layout", c_i), ("ab_dtype", c_i), ("c_dtype", c_i),
+                ("batch", c_i), ("batch_inner", c_i),
+                ("sA0", c_i64), ("sA1", c_i64), ("sB0", c_i64), ("sB1", c_i64), ("sC0", c_i64), ("sC1", c_i64),
+                ("alpha", c_f), ("accumulate", c_i), ("act", c_i), ("force_generic", c_i)]
+
+
+ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
+
+
+def gemm_raw(A, B, C, M, N, K, lda, ldb, ldc, a_layout=0, b_layout=0, bias=None, residual=None, ldr=0,
+             act=0, alpha=1.0, accumulate=False, batch=1, batch_inner=1, strides=(0, 0, 0, 0, 0, 0), force_generic=False):
+    """C = act(alpha*A.B + bias) + residual (+C).  A/B/C are tensors whose data_ptr() is the first
+    element of the (first) operand; all strides in elements.  See include/egomi.h."""
+    if A.dtype != B.dtype:
+        raise TypeError("gemm: A and B dtypes differ")
+    d = GemmDesc()
+    d.A, d.B, d.C = A.data_ptr(), B.data_ptr(), C.data_ptr()
+    d.bias = bias.data_ptr() if bias is not None else None
+    d.residual = residual.data_ptr() if residual is not None else None
+    if bias is not None and bias.dtype != A.dtype:
+        raise TypeError("gemm: bias dtype must equal the operand dtype")
+    if residual is not None and residual.dtype != C.dtype:
+        raise TypeError("gemm: residual dtype must equal the output dtype")
+    d.M, d.N, d.K = M, N, K
+    d.lda, d.ldb, d.ldc, d.ldr = lda, ldb, ldc, ldr
+    d.a_layout, d.b_layout = a_layout, b_layout
+    d.ab_dtype, d.c_dtype = dt(A.dtype), dt(C.dtype)
+    d.batch, d.batch_inner = batch, batch_inner
+    d.sA0, d.sA1, d.sB0, d.sB1, d.sC0, d.sC1 = strides
+    d.alpha, d.accumulate, d.act, d.force_generic = alpha, int(accumulate), act, int(force_generic)
+    for t in (A, B, C):
+        if not t.is_cuda:
+            raise _lib.EgomiError("gemm needs device tensors")
+    call("egomi_gemm", ctypes.byref(d), S())
+    return C
+
+
+def _ld(t):
+    if t.dim() != 2 or (t.shape[1] != 1 and t.stride(1) != 1):
+        raise ValueError("expected a 2-D view with unit inner stride")
+    return max(t.stride(0), t.shape[1]) if t.shape[0] > 1 else t.shape[1]
+
+
+def mm(a, b, out=None, a_layout=0, b_layout=0, out_dtype=None, **kw):
+    """2-D product on views with unit inner stride.  a: [M,K] (layout 0) or [K,M] (1);
+    b: [N,K] (layout 0, nn.Linear weight) or [K,N] (1)."""
+    M, K = (a.shape if a_layout == 0 else (a.shape[1], a.shape[0]))
+    N, Kb = (b.shape if b_layout == 0 else (b.shape[1], b.shape[0]))
+    if K != Kb:
+        raise ValueError(f"mm: inner dims differ ({K} vs {Kb})")
+    if out is None:
+        out = torch.empty(M, N, dtype=out_dtype or a.dtype, device=a.device)
+    res = kw.get("residual")
+    return gemm_raw(a, b, out, M, N, K, _ld(a), _ld(b), _ld(out), a_layout, b_layout,
+                    ldr=_ld(res) if res is not None else 0, **kw)
+
+
+# ------------------------------------------------------------------------------------------ rows
+def layernorm(x, w, b, eps=1e-5, add=None, sum_out=None, out=None):
+    rows, cols = x.numel() // x.shape[-1], x.shape[-1]
+    out = torch.empty_like(x) if out is None else out
+    call("egomi_layernorm_fwd", P(x), P(add), P(w), P(b), P(sum_out), P(out), c_i(rows), c_i(cols), c_f(eps), c_i(dt(x.dtype)), S())
+    return out
+
+
+def rmsnorm(x, w, eps, rstd=None, out=None):
+    rows, cols = x.numel() // x.shape[-1], x.shape[-1]
+    out = torch.empty_like(x) if out is None else out
+    call("egomi_rmsnorm_fwd", P(x), P(w), P(out), P(rstd), c_i(rows), c_i(cols), c_f(eps), c_i(dt(x.dtype)), S())
+    return out
+
+
+def rmsnorm_bwd(dy, x, w, rstd, dx_add=None, dw=None, out=None):
+    rows, cols = x.numel() // x.shape[-1], x.shape[-1]
+    out = torch.empty_like(x) if out is None else out
+    call("egomi_rmsnorm_bwd", P(dy), P(x), P(w), P(rstd), P(out), P(dx_add), P(dw), c_i(rows), c_i(cols), c_i(dt(x.dtype)), S())
+    return out
+
+
+def rope_tables(seq, head_dim, theta):
+    """fp32 cos/sin [S, hd/2], computed exactly as HF LlamaRotaryEmbedding does (modeling_llama.py:93-127)."""
+    inv = 1.0 / (theta ** (torch.arange(0, head_dim, 2, dtype=torch.float32) / head_dim))
+    freqs = torch.arange(seq, dtype=torch.float32)[:, None] * inv[None, :]
+    return freqs.cos().contiguous(), freqs.sin().contiguous()
+
+
+def rope_(x, cos, sin, rows, seq, pos_offset, H, hd, ld, inverse=False):
+    call("egomi_rope", P(x), P(cos), P(sin), c_i64(rows), c_i(seq), c_i(pos_offset), c_i(H), c_i(hd), c_i64(ld), c_i(int(inverse)), c_i(dt(x.dtype)), S())
+    return x
+
+
+def swiglu(gate, up, out):
+    rows, cols = gate.shape
+    call("egomi_swiglu_fwd", P(gate), P(up), P(out), c_i64(rows), c_i(cols), c_i64(_ld(gate)), c_i64(_ld(out)), c_i(dt(gate.dtype)), S())
+    return out
+
+
+def swiglu_bwd(dact, gate, up, dgate, dup):
+    rows, cols = gate.shape
+    call("egomi_swiglu_bwd", P(dact), P(gate), P(up), P(dgate), P(dup), c_i64(rows), c_i(cols), c_i64(_ld(gate)), c_i64(_ld(dact)),
+         c_i64(_ld(dgate)), c_i(dt(gate.dtype)), S())
+
+
+def gelu(x, out=None):
+    out = torch.empty_like(x) if out is None else out
+    call("egomi_gelu_fwd", P(x), P(out), c_i64(x.numel()), c_i(dt(x.dtype)), S())
+    return out
+
+
+def gelu_bwd(dy, x, out=None):
+    out = torch.empty_like(x) if out is None else out
+    call("egomi_gelu_bwd", P(dy), P(x), P(out), c_i64(x.numel()), c_i(dt(x.dtype)), S())
+    return out
+
+
+def softmax(scores, Z, heads, Sq, Sk, out, causal=False, q_offset=0, key_mask=None):
+    call("egomi_softmax_fwd", P(scores), c_i64(Sk), P(key_mask), c_i(Z), c_i(heads), c_i(Sq), c_i(Sk), c_i(int(causal)), c_i(q_offset),
+         P(out), c_i64(Sk), c_i(dt(out.dtype)), S())
+    return out
+
+
+def softmax_bwd(Pm, dP, dS, rows, Sk):
+    call("egomi_softmax_bwd", P(Pm), c_i64(Sk), P(dP), c_i64(Sk), P(dS), c_i64(Sk), c_i64(rows), c_i(Sk), c_i(dt(Pm.dtype)), S())
+    return dS
+
+
+def splice_scan(ids, tok, Pn):
+    B, Sl = ids.shape
+    sp = torch.empty(B, dtype=torch.int32, device=ids.device)
+    err = torch.empty(B, dtype=torch.int32, device=ids.device)
+    call("egomi_splice_scan", P(ids), c_i(B), c_i(Sl), c_i64(tok.point_patch), c_i64(tok.point_start), c_i64(tok.point_end), c_i(Pn), P(sp), P(err), S())
+    return sp, err
+
+
+def embed_splice(ids, W, feats, start_pos, Pn, out=None):
+    B, Sl = ids.shape
+    V, d = W.shape
+    out = torch.empty(B, Sl, d, dtype=W.dtype, device=W.device) if out is None else out
+    call("egomi_embed_splice_fwd", P(ids), P(W), P(feats), P(start_pos), c_i(B), c_i(Sl), c_i(d), c_i(Pn), c_i(V), P(out), c_i(dt(W.dtype)), S())
+    return out
+
+
+def embed_splice_bwd(dout, ids, start_pos, Pn, V, dW=None, dfeats=None):
+    B, Sl, d = dout.shape
+    call("egomi_embed_splice_bwd", P(dout), P(ids), P(start_pos), c_i(B), c_i(Sl), c_i(d), c_i(Pn), c_i(V), P(dW), P(dfeats), c_i(dt(dout.dtype)), S())
+
+
+def cross_entropy(logits, targets, ignore_index, dlogits=None, grad_scale=1.0):
+    """Returns (loss_sum fp32 [1], count i32 [1]); mean loss = loss_sum / count."""
+    R, V = logits.shape
+    cnt = torch.zeros(1, dtype=torch.int32, device=logits.device)
+    ls = torch.zeros(1, dtype=torch.float32, device=logits.device)
+    call("egomi_ce_count", P(targets), c_i64(R), c_i64(ignore_index), P(cnt), S())
+    call("egomi_ce_fwd_bwd", P(logits), c_i64(_ld(logits)), P(targets), c_i(R), c_i(V), c_i64(ignore_index), P(cnt), P(ls),
+         P(dlogits), c_i64(_ld(dlogits) if dlogits is not None else 0), c_f(grad_scale), c_i(dt(logits.dtype)), S())
+    return ls, cnt
+
+
+def adamw(master, model_copy, grad, m, v, lr, beta1, beta2, eps, wd, step, grad_scale=1.0):
+    call("egomi_adamw", P(master), P(model_copy), P(grad), P(m), P(v), c_i64(master.numel()), c_f(lr), c_f(beta1), c_f(beta2), c_f(eps),
+         c_f(wd), c_i(step), c_f(grad_scale), c_i(dt(model_copy.dtype) if model_copy is not None else F32), S())
+
+
+def transpose(x, ldo=None, out=None):
+    R, C = x.shape
+    ldo = R if ldo is None else ldo
+    out = torch.empty(C, ldo, dtype=x.dtype, device=x.device) if out is None else out
+    call("egomi_transpose", P(x), c_i(R), c_i(C), c_i64(_ld(x)), P(out), c_i64(ldo), c_i(dt(x.dtype)), S())
+    return out
+
+
+def cast(x, dtype, out=None):
+    out = torch.empty(x.shape, dtype=dtype, device=x.device) if out is None else out
+    call("egomi_cast", P(x), c_i(dt(x.dtype)), P(out), c_i(dt(dtype)), c_i64(x.numel()), S())
+    return out
+
+
+def add(a, b, out=None):
+    out = torch.empty_like(a) if out is None else out
+    call("egomi_add", P(a), P(b), P(out), c_i64(a.numel()), c_i(dt(a.dtype)), S())
+    return out
+
+
+def group_max(x, BG, M, C, concat=False, out=None):
+    if out is None:
+        out = torch.empty((BG * M, 2 * C) if concat else (BG, C), dtype=x.dtype, device=x.device)
+    call("egomi_group_max", P(x), c_i(BG), c_i(M), c_i(C), P(out), c_i(int(concat)), c_i(dt(x.dtype)), S())
+    return out
+
+
+def linear_smallk(x, w, b, act=0, out=None):
+    R, K = x.numel() // x.shape[-1], x.shape[-1]
+    N = w.shape[0]
+    out = torch.empty(R, N, dtype=w.dtype, device=w.device) if out is None else out
+    call("egomi_linear_smallk", P(x), c_i(dt(x.dtype)), P(w), P(b), P(out), c_i64(R), c_i(N), c_i(K), c_i(act), c_i(dt(w.dtype)), S())
+    return out

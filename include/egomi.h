@@ -83,6 +83,118 @@ int egomi_fps(const float* pts, int B, int N, int C, const int32_t* start, int G
 int egomi_knn_group(const float* pts, const float* center, int B, int N, int C, int G, int K,
                     int32_t* out_idx, void* out_nb, int out_dtype, egomi_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Dense products (MFMA).  replaces the aten linear/matmul calls inside
+ *   pointbert/dvae.py:193-204 (1x1 convs, A6), pointbert/point_encoder.py:14-18,38-40 (A8),
+ *   model/pointllm.py:67-81 (point_proj, A9), HF modeling_llama.py:174-176,243-281 (A11),
+ *   model/pointllm.py:187,227-228 (lm_head, A12) and their autograd backward.
+ *
+ *   C[M,N] = act(alpha * A.B + bias) + residual  (+ C when accumulate)
+ * a_layout 0: A is [M,K] row-major;  1: A is [K,M]
+ * b_layout 0: B is [N,K] row-major (nn.Linear weight); 1: B is [K,N]
+ * ab_dtype F32 (exact fp32 MFMA) or BF16 (fp32 accumulate); c_dtype F32 or BF16 (F32 inputs need
+ * F32 output).  bias [N] has ab_dtype; residual [M,N] (ldr) has c_dtype.  act: 0 none, 1 GELU(erf),
+ * 2 ReLU.  Batched: grid z in [0,batch): z0 = z / batch_inner, z1 = z % batch_inner, operand
+ * pointers advance by z0*s?0 + z1*s?1 ELEMENTS (residual uses C's strides).
+ */
+typedef struct egomi_gemm_desc {
+    const void* A; const void* B; void* C; const void* bias; const void* residual;
+    int M, N, K;
+    int64_t lda, ldb, ldc, ldr;
+    int a_layout, b_layout;
+    int ab_dtype, c_dtype;
+    int batch, batch_inner;
+    int64_t sA0, sA1, sB0, sB1, sC0, sC1;
+    float alpha;
+    int accumulate;
+    int act;
+    int force_generic;   /* 1: never take the tuned kernel (used by tests to cross-check it) */
+} egomi_gemm_desc;
+int egomi_gemm(const egomi_gemm_desc* desc, egomi_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Row / elementwise kernels (HBM-bound).  `dtype` is the activation/parameter dtype T.
+ */
+/* LayerNorm forward with optional fused pre-add: s = x (+ add); y = (s-mean)*rstd*w + b; sum_out = s
+ * replaces nn.LayerNorm in pointbert/point_encoder.py:60,63,142 and the `x + pos` of :95-98 */
+int egomi_layernorm_fwd(const void* x, const void* add, const void* w, const void* b, void* sum_out, void* y,
+                        int rows, int cols, float eps, int dtype, egomi_stream_t stream);
+
+/* RMSNorm.  replaces HF LlamaRMSNorm, transformers/models/llama/modeling_llama.py:53-67 (A11).
+ * fwd: y = w * T(x * rsqrt(mean(x^2)+eps)); rstd [rows] saved when non-NULL.  cols % 8 == 0.
+ * bwd: dx = dx_add + rstd*(w*dy - x_hat*mean(w*dy*x_hat)); dw [cols] fp32 += sum_rows dy*x_hat
+ *      (dx_add, dw may be NULL).  cols <= 8192. */
+int egomi_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd, int rows, int cols, float eps, int dtype,
+                      egomi_stream_t stream);
+int egomi_rmsnorm_bwd(const void* dy, const void* x, const void* w, const float* rstd, void* dx, const void* dx_add,
+                      float* dw, int rows, int cols, int dtype, egomi_stream_t stream);
+
+/* RoPE in place on x [rows, H, hd] (row stride ld elements); position of row r = pos_offset + r % S;
+ * cos/sin tables fp32 [>= pos_offset+S, hd/2].  inverse=1 applies the transposed rotation (backward).
+ * replaces HF rotate_half/apply_rotary_pos_emb, modeling_llama.py:130-160 (tables: :112-127) */
+int egomi_rope(void* x, const float* cos_tab, const float* sin_tab, int64_t rows, int S, int pos_offset, int H, int hd,
+               int64_t ld, int inverse, int dtype, egomi_stream_t stream);
+
+/* SwiGLU: out = silu(gate)*up.  replaces HF LlamaMLP.forward, modeling_llama.py:174-176.
+ * gate/up [rows, cols] with row stride ld_in; out / dgate / dup row stride ld_out; dact row stride ld_act. */
+int egomi_swiglu_fwd(const void* gate, const void* up, void* out, int64_t rows, int cols, int64_t ld_in, int64_t ld_out,
+                     int dtype, egomi_stream_t stream);
+int egomi_swiglu_bwd(const void* dact, const void* gate, const void* up, void* dgate, void* dup, int64_t rows, int cols,
+                     int64_t ld_in, int64_t ld_act, int64_t ld_out, int dtype, egomi_stream_t stream);
+
+/* exact (erf) GELU and its derivative.  replaces nn.GELU in point_proj, model/pointllm.py:72-76 */
+int egomi_gelu_fwd(const void* x, void* y, int64_t n, int dtype, egomi_stream_t stream);
+int egomi_gelu_bwd(const void* dy, const void* x, void* dx, int64_t n, int dtype, egomi_stream_t stream);
+
+/* Row softmax of fp32 scores [Z*Sq, Sk] (row stride ld_s) -> P (dtype, row stride ld_p).
+ * key j is visible to query i iff (!causal || j <= q_offset+i) && (key_mask == NULL || key_mask[b*Sk+j]),
+ * b = z / heads.  replaces pointbert/point_encoder.py:48-50 and HF eager_attention_forward,
+ * modeling_llama.py:204-210.  Sk <= 2048.   bwd: dS = P*(dP - sum_j P*dP). */
+int egomi_softmax_fwd(const float* scores, int64_t ld_s, const uint8_t* key_mask, int Z, int heads, int Sq, int Sk, int causal,
+                      int q_offset, void* P, int64_t ld_p, int dtype, egomi_stream_t stream);
+int egomi_softmax_bwd(const void* P, int64_t ld_p, const float* dP, int64_t ld_dp, void* dS, int64_t ld_ds, int64_t rows, int Sk,
+                      int dtype, egomi_stream_t stream);
+
+/* A10  point-token splice.  replaces model/pointllm.py:131-171 (mm_use_point_start_end=True).
+ * splice_scan: per sample start_pos = position of <point_start> (-1: text-only sample) and
+ * err: 0 ok | 1 start/end count mismatch (:146) | 2 <point_end> not at start+P+1 (:150) |
+ * 3 more than one point segment (unsupported here).
+ * embed_splice_fwd: out[b,s] = feats[b, s-start-1] if start < s <= start+P else W[ids[b,s]]
+ * (embedding lookup :107 + torch.cat splice :155).  bwd: dW (fp32 [V,d]) += rows outside the span,
+ * dfeats = rows inside it.  feats/start_pos/dW/dfeats may be NULL. */
+int egomi_splice_scan(const int64_t* ids, int B, int S, int64_t patch_id, int64_t start_id, int64_t end_id, int P,
+                      int32_t* start_pos, int32_t* err, egomi_stream_t stream);
+int egomi_embed_splice_fwd(const int64_t* ids, const void* W, const void* feats, const int32_t* start_pos, int B, int S, int d,
+                           int P, int V, void* out, int dtype, egomi_stream_t stream);
+int egomi_embed_splice_bwd(const void* dout, const int64_t* ids, const int32_t* start_pos, int B, int S, int d, int P, int V,
+                           float* dW, void* dfeats, int dtype, egomi_stream_t stream);
+
+/* A12  cross-entropy with ignore_index, mean over kept rows.  replaces F.cross_entropy at
+ * models/pointllm/train.py:174-181.  count must be zeroed, then ce_count, then ce_fwd_bwd:
+ * loss_sum (fp32, zeroed by caller) += sum_rows -log p[target]; dlogits (may alias logits, may be
+ * NULL) = (softmax - onehot) * grad_scale / count. */
+int egomi_ce_count(const int64_t* targets, int64_t n, int64_t ignore, int32_t* count, egomi_stream_t stream);
+int egomi_ce_fwd_bwd(const void* logits, int64_t ld, const int64_t* targets, int R, int V, int64_t ignore, const int32_t* count,
+                     float* loss_sum, void* dlogits, int64_t ldd, float grad_scale, int dtype, egomi_stream_t stream);
+
+/* AdamW step (torch.optim.AdamW semantics; reference optimizer models/pointllm/train.py:107-111).
+ * fp32 master/moments/grad; model_copy (copy_dtype, may be NULL) receives the updated value. */
+int egomi_adamw(float* master, void* model_copy, const float* grad, float* m, float* v, int64_t n, float lr, float beta1,
+                float beta2, float eps, float weight_decay, int step, float grad_scale, int copy_dtype, egomi_stream_t stream);
+
+/* layout helpers: out[c, r] = in[r, c] for r < R, zero for R <= r < ldo; cast; add */
+int egomi_transpose(const void* in, int R, int C, int64_t ldi, void* out, int64_t ldo, int dtype, egomi_stream_t stream);
+int egomi_cast(const void* in, int in_dtype, void* out, int out_dtype, int64_t n, egomi_stream_t stream);
+int egomi_add(const void* a, const void* b, void* out, int64_t n, int dtype, egomi_stream_t stream);
+
+/* A6 helpers.  group_max: x [BG, M, C] -> out [BG, C] (concat=0) or [BG*M, 2C] = [group max | x]
+ * (concat=1).  replaces torch.max / cat / expand at pointbert/dvae.py:216-219.
+ * linear_smallk: y = act(x.w^T + b) for K <= 8 (x may be fp32): pos_embed.0 (point_encoder.py:128)
+ * and the first 1x1 conv (dvae.py:194). */
+int egomi_group_max(const void* x, int BG, int M, int C, void* out, int concat, int dtype, egomi_stream_t stream);
+int egomi_linear_smallk(const void* x, int x_dtype, const void* w, const void* b, void* y, int64_t R, int N, int K, int act,
+                        int dtype, egomi_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,269 @@
+"""GPU: every dense / row kernel of libegomi.so against a plain PyTorch fp32 CPU evaluation of the
+same op.  fp32 kernels: <= 1e-4 relative to the output scale (target of the path: 1e-3);
+bf16 kernels: inputs are bf16-rounded first, tolerance 2e-2 of the output scale."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available()
+    from egoscaler_amd import ops as O
+    return O
+
+
+def close(got, ref, tol):
+    got, ref = got.float().cpu(), ref.float()
+    err = (got - ref).abs().max().item()
+    scale = ref.abs().max().item() + 1e-12
+    assert err <= tol * scale, f"max err {err:.3e} vs scale {scale:.3e} (tol {tol})"
+
+
+TOL = {torch.float32: 1e-4, torch.bfloat16: 2e-2}
+
+
+def rnd(*shape, dtype=torch.float32, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed + sum(shape))
+    return (torch.randn(*shape, generator=g) * scale).to(dtype)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 136, 96), (77, 53, 40), (513, 1152, 384), (1, 8, 8), (300, 32262 // 16, 128)])
+@pytest.mark.parametrize("al,bl", [(0, 0), (0, 1), (1, 0), (1, 1)])
+def test_gemm_layouts(ops, dtype, M, N, K, al, bl):
+    a = rnd(M, K, dtype=dtype, seed=1)
+    b = rnd(N, K, dtype=dtype, seed=2)
+    ref = a.float() @ b.float().t()
+    A = (a if al == 0 else a.t().contiguous()).cuda()
+    B = (b if bl == 0 else b.t().contiguous()).cuda()
+    out = ops.mm(A, B, a_layout=al, b_layout=bl)
+    close(out, ref, TOL[dtype])
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gemm_epilogues_and_views(ops, dtype):
+    M, N, K = 150, 200, 72
+    a, w, bias, res = rnd(M, K, dtype=dtype), rnd(N, K, dtype=dtype, seed=3), rnd(N, dtype=dtype, seed=4), rnd(M, N, dtype=dtype, seed=5)
+    A, W, Bi, R = a.cuda(), w.cuda(), bias.cuda(), res.cuda()
+    lin = a.float() @ w.float().t()
+    close(ops.mm(A, W, bias=Bi), lin + bias.float(), TOL[dtype])
+    close(ops.mm(A, W, bias=Bi, act=ops.ACT_GELU), F.gelu(lin + bias.float()), TOL[dtype])
+    close(ops.mm(A, W, bias=Bi, act=ops.ACT_RELU), F.relu(lin + bias.float()), TOL[dtype])
+    close(ops.mm(A, W, bias=Bi, residual=R, alpha=0.5), 0.5 * lin + bias.float() + res.float(), TOL[dtype])
+    # output into a column slice of a wider buffer (ldc > N), fp32 accumulate on top of existing C
+    big = torch.zeros(M, 3 * N, dtype=dtype, device="cuda")
+    ops.mm(A, W, out=big[:, N:2 * N])
+    close(big[:, N:2 * N], lin, TOL[dtype])
+    assert float(big[:, :N].abs().max()) == 0 and float(big[:, 2 * N:].abs().max()) == 0
+    acc = torch.ones(M, N, dtype=torch.float32, device="cuda")
+    ops.mm(A, W, out=acc, accumulate=True)
+    close(acc, lin + 1.0, TOL[dtype])
+    # unaligned operand (odd leading dimension) goes through the guarded path
+    wide = torch.zeros(M, K + 3, dtype=dtype, device="cuda")
+    wide[:, 1:K + 1] = A
+    close(ops.mm(wide[:, 1:K + 1], W), lin, TOL[dtype])
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gemm_batched_attention_pattern(ops, dtype):
+    Bq, H, Sq, hd = 2, 3, 70, 32
+    d = H * hd
+    qkv = rnd(Bq, Sq, 3 * d, dtype=dtype, seed=7)
+    Q = qkv.cuda()
+    sc = torch.empty(Bq * H, Sq, Sq, dtype=torch.float32, device="cuda") if dtype == torch.bfloat16 else torch.empty(Bq * H, Sq, Sq, device="cuda")
+    q, k, v = Q[:, :, :d], Q[:, :, d:2 * d], Q[:, :, 2 * d:]
+    ops.gemm_raw(q, k, sc, Sq, Sq, hd, 3 * d, 3 * d, Sq, 0, 0, alpha=0.25, batch=Bq * H, batch_inner=H,
+                 strides=(Sq * 3 * d, hd, Sq * 3 * d, hd, H * Sq * Sq, Sq * Sq))
+    qf = qkv.float().view(Bq, Sq, 3, H, hd)
+    ref = torch.einsum("bqhd,bkhd->bhqk", qf[:, :, 0], qf[:, :, 1]) * 0.25
+    close(sc.view(Bq, H, Sq, Sq), ref, TOL[dtype])
+    # P.V with V as the [K,N] operand, output written head-interleaved [B,S,H,hd]
+    Pm = torch.softmax(ref, -1).to(dtype)
+    out = torch.empty(Bq, Sq, d, dtype=dtype, device="cuda")
+    ops.gemm_raw(Pm.cuda(), v, out, Sq, hd, Sq, Sq, 3 * d, d, 0, 1, batch=Bq * H, batch_inner=H,
+                 strides=(H * Sq * Sq, Sq * Sq, Sq * 3 * d, hd, Sq * d, hd))
+    refo = torch.einsum("bhqk,bkhd->bqhd", Pm.float(), qf[:, :, 2]).reshape(Bq, Sq, d)
+    close(out, refo, TOL[dtype])
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_layernorm_and_rmsnorm(ops, dtype):
+    x, add, w, b = rnd(37, 384, dtype=dtype), rnd(37, 384, dtype=dtype, seed=1), rnd(384, dtype=dtype, seed=2), rnd(384, dtype=dtype, seed=3)
+    so = torch.empty(37, 384, dtype=dtype, device="cuda")
+    y = ops.layernorm(x.cuda(), w.cuda(), b.cuda(), 1e-5, add=add.cuda(), sum_out=so)
+    s = (x.float() + add.float()).to(dtype).float()
+    close(so, s, TOL[dtype])
+    close(y, F.layer_norm(s, (384,), w.float(), b.float(), 1e-5), TOL[dtype])
+    close(ops.layernorm(x.cuda(), w.cuda(), b.cuda()), F.layer_norm(x.float(), (384,), w.float(), b.float(), 1e-5), TOL[dtype])
+    # RMSNorm fwd/bwd vs autograd
+    R, C = 45, 512
+    xr, wr, dy, dadd = rnd(R, C, dtype=dtype, seed=4), (1 + 0.1 * rnd(C, seed=5)).to(dtype), rnd(R, C, dtype=dtype, seed=6), rnd(R, C, dtype=dtype, seed=7)
+    xf, wf = xr.float().requires_grad_(True), wr.float().requires_grad_(True)
+    yf = wf * (xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-6))
+    yf.backward(dy.float())
+    rstd = torch.empty(R, dtype=torch.float32, device="cuda")
+    close(ops.rmsnorm(xr.cuda(), wr.cuda(), 1e-6, rstd=rstd), yf.detach(), TOL[dtype])
+    dw = torch.zeros(C, dtype=torch.float32, device="cuda")
+    dx = ops.rmsnorm_bwd(dy.cuda(), xr.cuda(), wr.cuda(), rstd, dx_add=dadd.cuda(), dw=dw)
+    close(dx, xf.grad + dadd.float(), TOL[dtype])
+    close(dw, wf.grad, TOL[dtype])
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_rope_matches_oracle_and_inverse(ops, dtype):
+    from oracle import llama as OL
+    B, S, H, hd = 2, 19, 4, 32
+    q = rnd(B, S, H, hd, dtype=dtype)
+    cos, sin = OL.rope_cos_sin(S, hd, 10000.0, offset=3, dtype=dtype)
+    qo, _ = OL.apply_rope(q.transpose(1, 2), q.transpose(1, 2), cos, sin)
+    ct, st = ops.rope_tables(64, hd, 10000.0)
+    buf = torch.zeros(B * S, 3 * H * hd, dtype=dtype, device="cuda")
+    buf[:, H * hd:2 * H * hd] = q.reshape(B * S, H * hd).cuda()
+    view = buf[:, H * hd:2 * H * hd]
+    ops.rope_(view, ct.cuda(), st.cuda(), B * S, S, 3, H, hd, 3 * H * hd)
+    got = view.reshape(B, S, H, hd)
+    if dtype == torch.float32:
+        close(got, qo.transpose(1, 2), 1e-6)
+    else:
+        assert torch.equal(got.cpu(), qo.transpose(1, 2).contiguous()), "bf16 RoPE must reproduce HF's rounding sequence"
+    ops.rope_(view, ct.cuda(), st.cuda(), B * S, S, 3, H, hd, 3 * H * hd, inverse=True)
+    close(view.reshape(B, S, H, hd), q, 2e-2 if dtype == torch.bfloat16 else 1e-5)
+    assert float(buf[:, :H * hd].abs().max()) == 0
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_swiglu_gelu(ops, dtype):
+    R, Fd = 33, 352
+    gu, dact = rnd(R, 2 * Fd, dtype=dtype), rnd(R, Fd, dtype=dtype, seed=2)
+    g, u = gu[:, :Fd].float().requires_grad_(True), gu[:, Fd:].float().requires_grad_(True)
+    ref = F.silu(g) * u
+    ref.backward(dact.float())
+    GU = gu.cuda()
+    out = torch.empty(R, Fd, dtype=dtype, device="cuda")
+    ops.swiglu(GU[:, :Fd], GU[:, Fd:], out)
+    close(out, ref.detach(), TOL[dtype])
+    dgu = torch.empty(R, 2 * Fd, dtype=dtype, device="cuda")
+    ops.swiglu_bwd(dact.cuda(), GU[:, :Fd], GU[:, Fd:], dgu[:, :Fd], dgu[:, Fd:])
+    close(dgu[:, :Fd], g.grad, TOL[dtype])
+    close(dgu[:, Fd:], u.grad, TOL[dtype])
+    x = rnd(1000, dtype=dtype, seed=3, scale=2.0)
+    xf = x.float().requires_grad_(True)
+    y = F.gelu(xf)
+    y.backward(torch.ones_like(y) * 0.7)
+    close(ops.gelu(x.cuda()), y.detach(), TOL[dtype])
+    close(ops.gelu_bwd(torch.full_like(x, 0.7).cuda(), x.cuda()), xf.grad, TOL[dtype])
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_softmax_masks_and_backward(ops, dtype):
+    B, H, Sq, Sk = 2, 3, 17, 17
+    sc = rnd(B * H, Sq, Sk, seed=1, scale=3.0)
+    km = torch.ones(B, Sk, dtype=torch.uint8)
+    km[1, 12:] = 0
+    keep = torch.tril(torch.ones(Sq, Sk, dtype=torch.bool))[None, None] & km.bool()[:, None, None, :]
+    ref = torch.softmax(sc.view(B, H, Sq, Sk).masked_fill(~keep, float("-inf")), -1)
+    out = torch.empty(B * H, Sq, Sk, dtype=dtype, device="cuda")
+    ops.softmax(sc.cuda(), B * H, H, Sq, Sk, out, causal=True, key_mask=km.cuda())
+    close(out.view(B, H, Sq, Sk), ref, TOL[dtype])
+    out2 = torch.empty(B * H, Sq, Sk, dtype=dtype, device="cuda")
+    ops.softmax(sc.cuda(), B * H, H, Sq, Sk, out2)
+    close(out2, torch.softmax(sc, -1), TOL[dtype])
+    # decode row: one query at offset 9 sees keys 0..9
+    o3 = torch.empty(B * H, 1, Sk, dtype=dtype, device="cuda")
+    ops.softmax(sc[:, :1].contiguous().cuda(), B * H, H, 1, Sk, o3, causal=True, q_offset=9)
+    r3 = torch.softmax(sc[:, :1].masked_fill(torch.arange(Sk)[None, None] > 9, float("-inf")), -1)
+    close(o3, r3, TOL[dtype])
+    dP = rnd(B * H, Sq, Sk, seed=2)
+    Pm = torch.softmax(sc, -1).to(dtype)
+    dS = torch.empty_like(out2)
+    ops.softmax_bwd(Pm.cuda(), dP.cuda(), dS, B * H * Sq, Sk)
+    pf = Pm.float()
+    close(dS, pf * (dP - (pf * dP).sum(-1, keepdim=True)), TOL[dtype])
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_embed_splice_forward_backward_and_errors(ops, dtype):
+    from egoscaler_amd.config import dims_tiny
+    from egoscaler_amd import synth
+    from oracle import pointllm as OPL
+    dims = dims_tiny()
+    tok, Pn, d, V = dims.tok, dims.pb.point_token_len, 64, dims.lm.vocab_size
+    ids, _, _ = synth.synth_batch(dims, 3, text_len=8, num_steps=4, max_traj_token=40)
+    ids[2, (ids[2] >= tok.point_patch) & (ids[2] <= tok.point_end)] = 9          # text-only sample
+    W, feats = rnd(V, d, dtype=dtype), rnd(3, Pn, d, dtype=dtype, seed=1)
+    sp, err = ops.splice_scan(ids.cuda(), tok, Pn)
+    ref_pos = OPL.splice_positions(ids, tok, Pn)
+    assert err.cpu().tolist() == [0, 0, 0] and sp.cpu().tolist() == [p[0] if p else -1 for p in ref_pos]
+    out = ops.embed_splice(ids.cuda(), W.cuda(), feats.cuda(), sp, Pn)
+    ref = OPL.splice(ids, F.embedding(ids, W), feats, tok, Pn)
+    assert torch.equal(out.cpu(), ref), "splice is a pure copy: must be bit-exact"
+    dout = rnd(3, ids.shape[1], d, dtype=dtype, seed=2)
+    Wf, ff = W.float().requires_grad_(True), feats.float().requires_grad_(True)
+    OPL.splice(ids, F.embedding(ids, Wf), ff, tok, Pn).backward(dout.float())
+    dW = torch.zeros(V, d, dtype=torch.float32, device="cuda")
+    df = torch.zeros(3, Pn, d, dtype=dtype, device="cuda")
+    ops.embed_splice_bwd(dout.cuda(), ids.cuda(), sp, Pn, V, dW, df)
+    close(dW, Wf.grad, 1e-5)
+    close(df, ff.grad, 1e-6)
+    bad = ids.clone()
+    bad[0, (bad[0] == tok.point_end).nonzero()[0, 0]] = 5            # count mismatch (pointllm.py:146)
+    bad[1, (bad[1] == tok.point_end).nonzero()[0, 0]] = 5
+    bad[1, -1] = tok.point_end                                       # end token in the wrong place (:150)
+    _, err = ops.splice_scan(bad.cuda(), tok, Pn)
+    assert err.cpu().tolist() == [1, 2, 0]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_cross_entropy_ignore_index(ops, dtype):
+    R, V = 50, 1000
+    lg = rnd(R, V, dtype=dtype, scale=2.0)
+    tg = torch.randint(1, V, (R,), generator=torch.Generator().manual_seed(1))
+    tg[::7] = 0
+    lf = lg.float().requires_grad_(True)
+    loss = F.cross_entropy(lf, tg, ignore_index=0)
+    loss.backward()
+    dl = torch.empty(R, V, dtype=dtype, device="cuda")
+    ls, cnt = ops.cross_entropy(lg.cuda(), tg.cuda(), 0, dl)
+    assert int(cnt) == int((tg != 0).sum())
+    assert abs(float(ls) / int(cnt) - float(loss)) < 1e-4 * max(1, abs(float(loss)))
+    close(dl, lf.grad, TOL[dtype])
+
+
+def test_adamw_matches_torch(ops):
+    n = 5000
+    p0, g = rnd(n), rnd(n, seed=1)
+    p = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.AdamW([p], lr=2e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01)
+    master, m, v = p0.clone().cuda(), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    copy = torch.empty(n, dtype=torch.bfloat16, device="cuda")
+    for step in range(1, 4):
+        p.grad = g.clone() * step
+        opt.step()
+        ops.adamw(master, copy, (g * step).cuda(), m, v, 2e-3, 0.9, 0.999, 1e-8, 0.01, step)
+    close(master, p.detach(), 1e-5)
+    assert torch.equal(copy.cpu(), master.cpu().bfloat16())
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_transpose_cast_add_groupmax_smallk(ops, dtype):
+    x = rnd(70, 45, dtype=dtype)
+    t = ops.transpose(x.cuda(), ldo=96)
+    assert torch.equal(t[:, :70].cpu(), x.t()) and float(t[:, 70:].abs().max()) == 0
+    assert torch.equal(ops.cast(x.cuda(), torch.float32).cpu(), x.float())
+    assert torch.equal(ops.cast(x.float().cuda(), torch.bfloat16).cpu(), x.float().bfloat16())
+    close(ops.add(x.cuda(), x.cuda()), 2 * x.float(), TOL[dtype])
+    BG, M, C = 6, 16, 40
+    h = rnd(BG * M, C, dtype=dtype, seed=2)
+    hv = h.view(BG, M, C)
+    assert torch.equal(ops.group_max(h.cuda(), BG, M, C).cpu(), hv.max(1)[0])
+    cat = torch.cat([hv.max(1, keepdim=True)[0].expand(-1, M, -1), hv], -1).reshape(BG * M, 2 * C)
+    assert torch.equal(ops.group_max(h.cuda(), BG, M, C, concat=True).cpu(), cat)
+    xs, w, b = rnd(100, 3), rnd(128, 3, dtype=dtype, seed=3), rnd(128, dtype=dtype, seed=4)
+    close(ops.linear_smallk(xs.cuda(), w.cuda(), b.cuda(), act=ops.ACT_GELU), F.gelu(xs @ w.float().t() + b.float()), TOL[dtype])
+    x6 = rnd(64, 6, dtype=dtype, seed=5)
+    w6 = rnd(128, 6, dtype=dtype, seed=6)
+    close(ops.linear_smallk(x6.cuda(), w6.cuda(), b.cuda(), act=ops.ACT_RELU), F.relu(x6.float() @ w6.float().t() + b.float()), TOL[dtype])
