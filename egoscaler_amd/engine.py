@@ -1,0 +1,403 @@
+"""Explicit forward / backward of the EgoScaler trajectory generator over libegomi.so kernels.
+
+No tracing compiler and no torch autograd inside the path: every step below enqueues HIP kernels
+through the C-ABI (egoscaler_amd.ops) on the current stream, with activations kept resident in HBM
+buffers that are reused across steps (288 GB: nothing is recomputed, nothing is offloaded).
+
+Reference call stack this replaces:
+  pointllm/model/pointllm.py:90-178   PointLLMLlamaModel.forward  (encoder, projector, splice)
+  pointbert/point_encoder.py:169-189  PointTransformer.forward
+  HF modeling_llama.py:367-418        LlamaModel.forward (32 decoder layers)
+  pointllm/model/pointllm.py:227-228  lm_head ;  train.py:174-184  loss, backward
+"""
+import math
+from typing import Dict, List, Optional
+
+import torch
+
+from . import ops
+from .config import EgoDims
+
+
+class Workspace:
+    """Named device buffers reused across steps (shape/dtype changes re-allocate)."""
+
+    def __init__(self, device):
+        self.device = device
+        self.bufs: Dict[str, torch.Tensor] = {}
+
+    def get(self, name, shape, dtype, zero=False):
+        t = self.bufs.get(name)
+        shape = tuple(int(s) for s in shape)
+        if t is None or t.shape != shape or t.dtype != dtype:
+            t = torch.empty(shape, dtype=dtype, device=self.device)
+            self.bufs[name] = t
+            if zero:
+                t.zero_()
+        elif zero:
+            t.zero_()
+        return t
+
+    def bytes(self):
+        return sum(t.numel() * t.element_size() for t in self.bufs.values())
+
+
+class Engine:
+    def __init__(self, dims: EgoDims, params: Dict[str, torch.Tensor], device, dtype):
+        self.dims, self.w, self.device, self.dtype = dims, params, device, dtype
+        self.ws = Workspace(device)
+        self.prepared = False
+        self.main_grad: Dict[str, torch.Tensor] = {}     # fp32 gradient buffers of trainable tensors
+        self.trainable: Dict[str, bool] = {}
+        self.ctx = None
+
+    # ------------------------------------------------------------------------------------ setup
+    def prepare(self):
+        """One-time derived weights: BatchNorm (eval) folded into the mini-PointNet convs
+        (dvae.py:193-204 with running stats, model_arch.py:121-122), RoPE tables."""
+        w, pb, lm = self.w, self.dims.pb, self.dims.lm
+        pre = "model.point_backbone.encoder."
+        f = {}
+        for conv, bn, key in (("first_conv.0", "first_conv.1", "c1"), ("second_conv.0", "second_conv.1", "c3")):
+            W = w[pre + conv + ".weight"].float().squeeze(-1)
+            b = w[pre + conv + ".bias"].float()
+            g, beta = w[pre + bn + ".weight"].float(), w[pre + bn + ".bias"].float()
+            mu, var = w[pre + bn + ".running_mean"].float(), w[pre + bn + ".running_var"].float()
+            s = g / torch.sqrt(var + pb.bn_eps)
+            f[key + "_w"] = (W * s[:, None]).to(self.dtype).contiguous()
+            f[key + "_b"] = ((b - mu) * s + beta).to(self.dtype).contiguous()
+        f["c2_w"] = w[pre + "first_conv.3.weight"].squeeze(-1).contiguous()
+        f["c4_w"] = w[pre + "second_conv.3.weight"].squeeze(-1).contiguous()
+        self.folded = f
+        cos, sin = ops.rope_tables(lm.max_position_embeddings, lm.head_dim, lm.rope_theta)
+        self.cos, self.sin = cos.to(self.device), sin.to(self.device)
+        self.prepared = True
+
+    def set_trainable(self, names):
+        self.trainable = {n: True for n in names}
+
+    def grad_buffer(self, name):
+        g = self.main_grad.get(name)
+        if g is None:
+            g = torch.zeros(self.w[name].shape, dtype=torch.float32, device=self.device)
+            self.main_grad[name] = g
+        return g
+
+    def zero_grad(self):
+        for g in self.main_grad.values():
+            g.zero_()
+
+    # ------------------------------------------------------------------------------------ pieces
+    def _attention(self, tag, qkv, B, S, H, hd, out, causal, key_mask, scale, keep_P, past=None):
+        """qkv [B*S, 3*H*hd]; out [B*S, H*hd].  Unfused: scores (fp32) -> softmax -> P.V, all on the
+        batched MFMA GEMM; no transposes, heads addressed by strides."""
+        d = H * hd
+        T = self.dtype
+        q, k, v = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
+        sc = self.ws.get("att_scores", (B * H, S, S), torch.float32)
+        ops.gemm_raw(q, k, sc, S, S, hd, 3 * d, 3 * d, S, 0, 0, alpha=scale, batch=B * H, batch_inner=H,
+                     strides=(S * 3 * d, hd, S * 3 * d, hd, H * S * S, S * S))
+        Pm = torch.empty(B * H, S, S, dtype=T, device=self.device) if keep_P else self.ws.get("att_P", (B * H, S, S), T)
+        ops.softmax(sc, B * H, H, S, S, Pm, causal=causal, key_mask=key_mask)
+        ops.gemm_raw(Pm, v, out, S, hd, S, S, 3 * d, d, 0, 1, batch=B * H, batch_inner=H,
+                     strides=(H * S * S, S * S, S * 3 * d, hd, S * d, hd))
+        return Pm
+
+    def _attention_bwd(self, qkv, Pm, d_out, dqkv, B, S, H, hd, scale):
+        d = H * hd
+        q, k, v = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
+        dq, dk, dv = dqkv[:, :d], dqkv[:, d:2 * d], dqkv[:, 2 * d:]
+        dP = self.ws.get("att_scores", (B * H, S, S), torch.float32)
+        ops.gemm_raw(d_out, v, dP, S, S, hd, d, 3 * d, S, 0, 0, batch=B * H, batch_inner=H,
+                     strides=(S * d, hd, S * 3 * d, hd, H * S * S, S * S))
+        dS = self.ws.get("att_dS", (B * H, S, S), self.dtype)
+        ops.softmax_bwd(Pm, dP, dS, B * H * S, S)
+        st_ss = (H * S * S, S * S)
+        ops.gemm_raw(dS, k, dq, S, hd, S, S, 3 * d, 3 * d, 0, 1, alpha=scale, batch=B * H, batch_inner=H,
+                     strides=(*st_ss, S * 3 * d, hd, S * 3 * d, hd))
+        ops.gemm_raw(dS, q, dk, S, hd, S, S, 3 * d, 3 * d, 1, 1, alpha=scale, batch=B * H, batch_inner=H,
+                     strides=(*st_ss, S * 3 * d, hd, S * 3 * d, hd))
+        ops.gemm_raw(Pm, d_out, dv, S, hd, S, S, d, 3 * d, 1, 1, batch=B * H, batch_inner=H,
+                     strides=(*st_ss, S * d, hd, S * 3 * d, hd))
+
+    # ------------------------------------------------------------------------------------ PointBERT
+    @torch.no_grad()
+    def point_backbone(self, pts: torch.Tensor, fps_start) -> torch.Tensor:
+        """pts [B,N,C] f32 -> [B, G+1, D] (dtype T).  Frozen/eval path (model_arch.py:33-36,121-122)."""
+        if not self.prepared:
+            self.prepare()
+        w, pb, T, ws = self.w, self.dims.pb, self.dtype, self.ws
+        pre = "model.point_backbone."
+        B, N, C = pts.shape
+        G, K, D, Pn = pb.num_group, pb.group_size, pb.trans_dim, pb.point_token_len
+        idx, center = ops.fps(pts, fps_start, G)                                   # A3
+        _, nb = ops.knn_group(pts, center, K, out_dtype=T)                         # A4+A5  [B,G,K,C]
+        f = self.folded
+        BG = B * G
+        h1 = ops.linear_smallk(nb.view(BG * K, C), f["c1_w"], f["c1_b"], act=ops.ACT_RELU,
+                               out=ws.get("pn_h1", (BG * K, pb.pn_c1), T))         # conv+BN+ReLU
+        h2 = ops.mm(h1, f["c2_w"], out=ws.get("pn_h2", (BG * K, pb.pn_c2), T), bias=w[pre + "encoder.first_conv.3.bias"])
+        cat = ops.group_max(h2, BG, K, pb.pn_c2, concat=True, out=ws.get("pn_cat", (BG * K, 2 * pb.pn_c2), T))
+        h3 = ops.mm(cat, f["c3_w"], out=ws.get("pn_h3", (BG * K, pb.pn_c3), T), bias=f["c3_b"], act=ops.ACT_RELU)
+        h4 = ops.mm(h3, f["c4_w"], out=ws.get("pn_h4", (BG * K, pb.encoder_dims), T), bias=w[pre + "encoder.second_conv.3.bias"])
+        tok = ops.group_max(h4, BG, K, pb.encoder_dims, out=ws.get("pn_tok", (BG, pb.encoder_dims), T))
+        # tokens + positional embedding, written straight into rows 1..G of [B, G+1, D]
+        x = ws.get("pb_x", (B, Pn, D), T)
+        pos = ws.get("pb_pos", (B, Pn, D), T)
+        x[:, 0] = w[pre + "cls_token"].view(1, D)
+        pos[:, 0] = w[pre + "cls_pos"].view(1, D)
+        ops.gemm_raw(tok, w[pre + "reduce_dim.weight"], x[:, 1:], G, D, pb.encoder_dims, pb.encoder_dims, pb.encoder_dims, D,
+                     bias=w[pre + "reduce_dim.bias"], batch=B, strides=(G * pb.encoder_dims, 0, 0, 0, Pn * D, 0))
+        ph = ops.linear_smallk(center.view(BG, 3), w[pre + "pos_embed.0.weight"], w[pre + "pos_embed.0.bias"], act=ops.ACT_GELU,
+                               out=ws.get("pb_ph", (BG, pb.pos_hidden), T))
+        ops.gemm_raw(ph, w[pre + "pos_embed.2.weight"], pos[:, 1:], G, D, pb.pos_hidden, pb.pos_hidden, pb.pos_hidden, D,
+                     bias=w[pre + "pos_embed.2.bias"], batch=B, strides=(G * pb.pos_hidden, 0, 0, 0, Pn * D, 0))
+        M = B * Pn
+        H, hd = pb.num_heads, pb.head_dim
+        xs = ws.get("pb_xs", (M, D), T)
+        h = ws.get("pb_h", (M, D), T)
+        qkv = ws.get("pb_qkv", (M, 3 * D), T)
+        ao = ws.get("pb_ao", (M, D), T)
+        x1 = ws.get("pb_x1", (M, D), T)
+        mid = ws.get("pb_mid", (M, pb.mlp_ratio * D), T)
+        xf = x.view(M, D)
+        for i in range(pb.depth):
+            p = f"{pre}blocks.blocks.{i}."
+            ops.layernorm(xf, w[p + "norm1.weight"], w[p + "norm1.bias"], pb.ln_eps, add=pos.view(M, D), sum_out=xs, out=h)
+            ops.mm(h, w[p + "attn.qkv.weight"], out=qkv)
+            self._attention("pb", qkv, B, Pn, H, hd, ao, False, None, hd ** -0.5, False)
+            ops.mm(ao, w[p + "attn.proj.weight"], out=x1, bias=w[p + "attn.proj.bias"], residual=xs)
+            ops.layernorm(x1, w[p + "norm2.weight"], w[p + "norm2.bias"], pb.ln_eps, out=h)
+            ops.mm(h, w[p + "mlp.fc1.weight"], out=mid, bias=w[p + "mlp.fc1.bias"], act=ops.ACT_GELU)
+            ops.mm(mid, w[p + "mlp.fc2.weight"], out=xf, bias=w[p + "mlp.fc2.bias"], residual=x1)
+        out = torch.empty(B, Pn, D, dtype=T, device=self.device)
+        ops.layernorm(xf, w[pre + "norm.weight"], w[pre + "norm.bias"], pb.ln_eps, out=out.view(M, D))
+        return out
+
+    # ------------------------------------------------------------------------------------ forward
+    def forward_hidden(self, input_ids, attention_mask, point_clouds, fps_start, save=True, kv_cache=None):
+        """-> final-normed hidden [B*S, d]; fills self.ctx for backward when save=True."""
+        if not self.prepared:
+            self.prepare()
+        w, dims, T, ws = self.w, self.dims, self.dtype, self.ws
+        lm, pb, tok = dims.lm, dims.pb, dims.tok
+        B, S = input_ids.shape
+        d, Fd, H, hd, L = lm.hidden_size, lm.intermediate_size, lm.num_attention_heads, lm.head_dim, lm.num_hidden_layers
+        M = B * S
+        Pn = pb.point_token_len
+        ctx = {"B": B, "S": S, "ids": input_ids, "layers": []} if save else None
+        past = 0 if kv_cache is None else kv_cache["len"]
+        # ---- point branch (pointllm.py:112-129): only when S != 1 (prefill / training)
+        feats_proj, start_pos = None, None
+        if point_clouds is not None and S != 1:
+            if isinstance(point_clouds, (list, tuple)):                          # pointllm.py:117-122
+                fl = [self.point_backbone(pc[None].to(self.device, torch.float32), [int(fps_start[i])]) for i, pc in enumerate(point_clouds)]
+                feats = torch.cat(fl, 0)
+            else:
+                feats = self.point_backbone(point_clouds.to(self.device, torch.float32), fps_start)
+            fm = feats.view(B * Pn, pb.trans_dim)
+            acts = [fm]
+            nh = len(pb.projection_hidden_dim)
+            cur = fm
+            for j in range(nh):                                                    # pointllm.py:67-81
+                Wj, bj = w[f"model.point_proj.{2 * j}.weight"], w[f"model.point_proj.{2 * j}.bias"]
+                pre_act = ops.mm(cur, Wj, bias=bj, out=ws.get(f"pp_pre{j}", (B * Pn, Wj.shape[0]), T))
+                cur = ops.gelu(pre_act, out=ws.get(f"pp_act{j}", (B * Pn, Wj.shape[0]), T))
+                acts += [pre_act, cur]
+            Wl, bl = w[f"model.point_proj.{2 * nh}.weight"], w[f"model.point_proj.{2 * nh}.bias"]
+            feats_proj = ops.mm(cur, Wl, bias=bl, out=ws.get("pp_out", (B * Pn, d), T))
+            sp, err = ops.splice_scan(input_ids, tok, Pn)
+            e = err.cpu()                                                          # the reference syncs here too (pointllm.py:137)
+            if int(e.max()) != 0:
+                code = int(e[e != 0][0])
+                if code == 1:
+                    raise ValueError("The number of point start tokens and point end tokens should be the same.")
+                if code == 2:
+                    raise ValueError("The point end token should follow the point start token.")
+                raise NotImplementedError("more than one point segment per sample is not supported by this build")
+            start_pos = sp
+            if save:
+                ctx["pp_acts"] = acts
+        if save:
+            ctx["start_pos"] = start_pos
+            ctx["has_points"] = feats_proj is not None
+        x = ws.get("x_emb", (B, S, d), T) if not save else torch.empty(B, S, d, dtype=T, device=self.device)
+        ops.embed_splice(input_ids, w["model.embed_tokens.weight"], feats_proj, start_pos, Pn, out=x)
+        x = x.view(M, d)
+        key_mask = None
+        if attention_mask is not None:
+            key_mask = attention_mask.to(device=self.device, dtype=torch.uint8).contiguous()
+        scale = hd ** -0.5
+        for l in range(L):
+            p = f"model.layers.{l}."
+            if save:
+                lc = {"x_in": x, "rstd1": torch.empty(M, dtype=torch.float32, device=self.device),
+                      "rstd2": torch.empty(M, dtype=torch.float32, device=self.device),
+                      "qkv": torch.empty(M, 3 * d, dtype=T, device=self.device),
+                      "gu": torch.empty(M, 2 * Fd, dtype=T, device=self.device)}
+                keep_in = self.any_layer_trainable
+                h = torch.empty(M, d, dtype=T, device=self.device) if keep_in else ws.get("h", (M, d), T)
+                ao = torch.empty(M, d, dtype=T, device=self.device) if keep_in else ws.get("ao", (M, d), T)
+                h2 = torch.empty(M, d, dtype=T, device=self.device) if keep_in else ws.get("h2", (M, d), T)
+                act = torch.empty(M, Fd, dtype=T, device=self.device) if keep_in else ws.get("act", (M, Fd), T)
+                x_mid = torch.empty(M, d, dtype=T, device=self.device)
+                x_out = torch.empty(M, d, dtype=T, device=self.device)
+                qkv, gu, rstd1, rstd2 = lc["qkv"], lc["gu"], lc["rstd1"], lc["rstd2"]
+            else:
+                h, ao, h2, act = ws.get("h", (M, d), T), ws.get("ao", (M, d), T), ws.get("h2", (M, d), T), ws.get("act", (M, Fd), T)
+                x_mid, x_out = ws.get("x_mid", (M, d), T), ws.get(f"x_out{l & 1}", (M, d), T)
+                qkv, gu, rstd1, rstd2 = ws.get("qkv", (M, 3 * d), T), ws.get("gu", (M, 2 * Fd), T), None, None
+            ops.rmsnorm(x, w[p + "input_layernorm.weight"], lm.rms_norm_eps, rstd=rstd1, out=h)
+            ops.mm(h, w[p + "self_attn.q_proj.weight"], out=qkv[:, :d])
+            ops.mm(h, w[p + "self_attn.k_proj.weight"], out=qkv[:, d:2 * d])
+            ops.mm(h, w[p + "self_attn.v_proj.weight"], out=qkv[:, 2 * d:])
+            ops.rope_(qkv[:, :d], self.cos, self.sin, M, S, past, H, hd, 3 * d)
+            ops.rope_(qkv[:, d:2 * d], self.cos, self.sin, M, S, past, H, hd, 3 * d)
+            if kv_cache is None:
+                Pm = self._attention("lm", qkv, B, S, H, hd, ao, True, key_mask, scale, save)
+            else:
+                Pm = None
+                self._attention_cached(l, qkv, B, S, H, hd, ao, key_mask, scale, kv_cache)
+            ops.mm(ao, w[p + "self_attn.o_proj.weight"], out=x_mid, residual=x)
+            ops.rmsnorm(x_mid, w[p + "post_attention_layernorm.weight"], lm.rms_norm_eps, rstd=rstd2, out=h2)
+            ops.mm(h2, w[p + "mlp.gate_proj.weight"], out=gu[:, :Fd])
+            ops.mm(h2, w[p + "mlp.up_proj.weight"], out=gu[:, Fd:])
+            ops.swiglu(gu[:, :Fd], gu[:, Fd:], act)
+            ops.mm(act, w[p + "mlp.down_proj.weight"], out=x_out, residual=x_mid)
+            if save:
+                lc.update(P=Pm, x_mid=x_mid, h=h, ao=ao, h2=h2, act=act)
+                ctx["layers"].append(lc)
+            x = x_out
+        if kv_cache is not None:
+            kv_cache["len"] = past + S
+        rstd_f = torch.empty(M, dtype=torch.float32, device=self.device) if save else None
+        hn = torch.empty(M, d, dtype=T, device=self.device)
+        ops.rmsnorm(x, w["model.norm.weight"], lm.rms_norm_eps, rstd=rstd_f, out=hn)
+        if save:
+            ctx.update(x_last=x, rstd_f=rstd_f, hn=hn, key_mask=key_mask)
+            self.ctx = ctx
+        return hn
+
+    def _attention_cached(self, l, qkv, B, S, H, hd, out, key_mask, scale, cache):
+        """Prefill (S>1) fills the cache; decode (S==1) attends against it (pointllm.py:255-275)."""
+        d = H * hd
+        past, Smax = cache["len"], cache["max"]
+        kc, vc = cache["k"][l], cache["v"][l]                     # [B, Smax, d]
+        kc[:, past:past + S] = qkv[:, d:2 * d].view(B, S, d)
+        vc[:, past:past + S] = qkv[:, 2 * d:].view(B, S, d)
+        Tk = past + S
+        q = qkv[:, :d]
+        sc = self.ws.get("att_scores_c", (B * H, S, Tk), torch.float32)
+        ops.gemm_raw(q, kc, sc, S, Tk, hd, 3 * d, d, Tk, 0, 0, alpha=scale, batch=B * H, batch_inner=H,
+                     strides=(S * 3 * d, hd, Smax * d, hd, H * S * Tk, S * Tk))
+        Pm = self.ws.get("att_P_c", (B * H, S, Tk), self.dtype)
+        km = None
+        if key_mask is not None:
+            km = key_mask[:, :Tk].contiguous()
+        ops.softmax(sc, B * H, H, S, Tk, Pm, causal=True, q_offset=past, key_mask=km)
+        ops.gemm_raw(Pm, vc, out, S, hd, Tk, Tk, d, d, 0, 1, batch=B * H, batch_inner=H,
+                     strides=(H * S * Tk, S * Tk, Smax * d, hd, S * d, hd))
+
+    def new_kv_cache(self, B, max_len):
+        lm = self.dims.lm
+        L, d = lm.num_hidden_layers, lm.hidden_size
+        return {"len": 0, "max": max_len,
+                "k": torch.zeros(L, B, max_len, d, dtype=self.dtype, device=self.device),
+                "v": torch.zeros(L, B, max_len, d, dtype=self.dtype, device=self.device)}
+
+    def logits(self, hn, rows=None):
+        """lm_head (pointllm.py:227-228).  hn [M,d] -> [M,V]."""
+        W = self.w["lm_head.weight"]
+        return ops.mm(hn, W, out=torch.empty(hn.shape[0], W.shape[0], dtype=self.dtype, device=self.device))
+
+    @property
+    def any_layer_trainable(self):
+        return any(n.startswith("model.layers.") for n in self.trainable)
+
+    # ------------------------------------------------------------------------------------ backward
+    def _wgrad(self, name, dY, X):
+        """main_grad[name] (fp32 [N,K]) += dY^T [N,M] . X [M,K]"""
+        if name in self.trainable:
+            ops.mm(dY, X, out=self.grad_buffer(name), a_layout=1, b_layout=1, accumulate=True)
+
+    def _bgrad(self, name, dY):
+        if name in self.trainable:
+            ones = self.ws.get("ones_col", (dY.shape[0], 8), dY.dtype)
+            if not getattr(self, "_ones_ready", None) == dY.shape[0]:
+                ones.fill_(1.0)
+                self._ones_ready = dY.shape[0]
+            g = self.grad_buffer(name)
+            tmp = self.ws.get("bgrad_tmp", (dY.shape[1], 8), torch.float32)
+            ops.mm(dY, ones, out=tmp, a_layout=1, b_layout=1)          # column sums on the MFMA path
+            g += tmp[:, 0]
+
+    def backward_hidden(self, d_hn):
+        """d_hn: gradient w.r.t. the final-normed hidden [M,d].  Accumulates fp32 main_grad of the
+        trainable tensors (model_arch.py:33-51 decides which)."""
+        ctx, w, dims, T, ws = self.ctx, self.w, self.dims, self.dtype, self.ws
+        lm, pb = dims.lm, dims.pb
+        B, S = ctx["B"], ctx["S"]
+        d, Fd, H, hd, L = lm.hidden_size, lm.intermediate_size, lm.num_attention_heads, lm.head_dim, lm.num_hidden_layers
+        M = B * S
+        scale = hd ** -0.5
+        tr = self.trainable
+        dw = self.grad_buffer("model.norm.weight") if "model.norm.weight" in tr else None
+        dx = ops.rmsnorm_bwd(d_hn, ctx["x_last"], w["model.norm.weight"], ctx["rstd_f"], dw=dw, out=ws.get("dx_a", (M, d), T))
+        for l in reversed(range(L)):
+            p = f"model.layers.{l}."
+            lc = ctx["layers"][l]
+            gu, qkv = lc["gu"], lc["qkv"]
+            # ---- MLP
+            d_act = ops.mm(dx, w[p + "mlp.down_proj.weight"], out=ws.get("d_act", (M, Fd), T), b_layout=1)
+            self._wgrad(p + "mlp.down_proj.weight", dx, lc["act"])
+            dgu = ws.get("dgu", (M, 2 * Fd), T)
+            ops.swiglu_bwd(d_act, gu[:, :Fd], gu[:, Fd:], dgu[:, :Fd], dgu[:, Fd:])
+            d_h2 = ops.mm(dgu[:, :Fd], w[p + "mlp.gate_proj.weight"], out=ws.get("d_h", (M, d), T), b_layout=1)
+            ops.mm(dgu[:, Fd:], w[p + "mlp.up_proj.weight"], out=d_h2, b_layout=1, residual=d_h2)
+            self._wgrad(p + "mlp.gate_proj.weight", dgu[:, :Fd], lc["h2"])
+            self._wgrad(p + "mlp.up_proj.weight", dgu[:, Fd:], lc["h2"])
+            n2 = p + "post_attention_layernorm.weight"
+            d_mid = ops.rmsnorm_bwd(d_h2, lc["x_mid"], w[n2], lc["rstd2"], dx_add=dx,
+                                    dw=self.grad_buffer(n2) if n2 in tr else None, out=ws.get("dx_b", (M, d), T))
+            # ---- attention
+            d_ao = ops.mm(d_mid, w[p + "self_attn.o_proj.weight"], out=ws.get("d_ao", (M, d), T), b_layout=1)
+            self._wgrad(p + "self_attn.o_proj.weight", d_mid, lc["ao"])
+            dqkv = ws.get("dqkv", (M, 3 * d), T)
+            self._attention_bwd(qkv, lc["P"], d_ao, dqkv, B, S, H, hd, scale)
+            ops.rope_(dqkv[:, :d], self.cos, self.sin, M, S, 0, H, hd, 3 * d, inverse=True)
+            ops.rope_(dqkv[:, d:2 * d], self.cos, self.sin, M, S, 0, H, hd, 3 * d, inverse=True)
+            d_h = ops.mm(dqkv[:, :d], w[p + "self_attn.q_proj.weight"], out=ws.get("d_h", (M, d), T), b_layout=1)
+            ops.mm(dqkv[:, d:2 * d], w[p + "self_attn.k_proj.weight"], out=d_h, b_layout=1, residual=d_h)
+            ops.mm(dqkv[:, 2 * d:], w[p + "self_attn.v_proj.weight"], out=d_h, b_layout=1, residual=d_h)
+            for i, nm in enumerate("qkv"):
+                self._wgrad(p + f"self_attn.{nm}_proj.weight", dqkv[:, i * d:(i + 1) * d], lc["h"])
+            n1 = p + "input_layernorm.weight"
+            dx = ops.rmsnorm_bwd(d_h, lc["x_in"], w[n1], lc["rstd1"], dx_add=d_mid,
+                                 dw=self.grad_buffer(n1) if n1 in tr else None, out=ws.get("dx_a", (M, d), T))
+        # ---- embedding + splice + projector (pointllm.py:107,126-129,155)
+        Pn = pb.point_token_len
+        V = lm.vocab_size
+        emb_name = "model.embed_tokens.weight"
+        d_feats = ws.get("d_pp_out", (B * Pn, d), T) if ctx["has_points"] else None
+        ops.embed_splice_bwd(dx.view(B, S, d), ctx["ids"], ctx["start_pos"], Pn, V,
+                             self.grad_buffer(emb_name) if emb_name in tr else None, d_feats)
+        if ctx["has_points"]:
+            acts = ctx["pp_acts"]
+            nh = len(pb.projection_hidden_dim)
+            g = d_feats
+            for j in range(nh, -1, -1):
+                Wn, bn = f"model.point_proj.{2 * j}.weight", f"model.point_proj.{2 * j}.bias"
+                x_in = acts[2 * j]                     # input of linear j: feats (j=0) or gelu output
+                self._wgrad(Wn, g, x_in)
+                self._bgrad(bn, g)
+                if j > 0:
+                    g_in = ops.mm(g, w[Wn], out=ws.get(f"d_pp_act{j}", (B * Pn, w[Wn].shape[1]), T), b_layout=1)
+                    g = ops.gelu_bwd(g_in, acts[2 * j - 1], out=ws.get(f"d_pp_pre{j}", g_in.shape, T))
+        self.ctx = None
+
+    def backward_logits(self, d_logits, hn):
+        """lm_head backward: d_hn = d_logits . W ; dW += d_logits^T . hn."""
+        W = self.w["lm_head.weight"]
+        d_hn = ops.mm(d_logits, W, out=self.ws.get("d_hn", hn.shape, self.dtype), b_layout=1)
+        self._wgrad("lm_head.weight", d_logits, hn)
+        return d_hn

@@ -1,0 +1,412 @@
+"""TrajPointLLMForCausalLM on MI355X.
+
+Mirrors egoscaler/models/pointllm/model_arch.py:8-124 (class, constructor arguments, freeze logic,
+narrow forward, generate wrapper, train(mode) override) and the parts of
+pointllm/model/pointllm.py it inherits (point_backbone_config :49-59,288-300; resize of the token
+embeddings used by builder.py:44).  State-dict keys and shapes are the reference's,
+so checkpoints round-trip.  All arithmetic runs in egoscaler_amd.engine on libegomi.so.
+"""
+import json
+import os
+from dataclasses import dataclass
+from typing import List, Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from ..config import EgoDims, LlamaDims, PointBertDims, SpecialTokens
+from ..engine import Engine
+from .. import ops, synth
+
+
+class PointLLMConfig:
+    """Duck-typed stand-in for the HF config the reference passes around (PointLLMConfig,
+    pointllm.py:23-24): plain attributes, readable from / writable to a HF-style config.json."""
+    model_type = "pointllm"
+
+    def __init__(self, **kw):
+        self.hidden_size = 4096
+        self.intermediate_size = 11008
+        self.num_hidden_layers = 32
+        self.num_attention_heads = 32
+        self.vocab_size = 32003
+        self.rms_norm_eps = 1e-6
+        self.rope_theta = 10000.0
+        self.max_position_embeddings = 2048
+        self.pad_token_id = 0
+        self.bos_token_id = 1
+        self.eos_token_id = 2
+        self.point_backbone = "PointBERT"
+        self.point_backbone_config_name = "PointTransformer_8192point_2layer"
+        self.use_color = True
+        self.mm_use_point_start_end = True
+        self.DEFAULT_POINT_PATCH_TOKEN = "<point_patch>"
+        self.DEFAULT_POINT_START_TOKEN = "<point_start>"
+        self.DEFAULT_POINT_END_TOKEN = "<point_end>"
+        self.point_bert = None            # optional dict overriding the PointBERT YAML values
+        self.__dict__.update(kw)
+
+    @classmethod
+    def from_pretrained(cls, path):
+        with open(os.path.join(path, "config.json")) as f:
+            return cls(**json.load(f))
+
+    def save_pretrained(self, path):
+        os.makedirs(path, exist_ok=True)
+        with open(os.path.join(path, "config.json"), "w") as f:
+            json.dump({k: v for k, v in self.__dict__.items()}, f, indent=1)
+
+    @classmethod
+    def from_dims(cls, dims: EgoDims):
+        pb = dims.pb
+        return cls(hidden_size=dims.lm.hidden_size, intermediate_size=dims.lm.intermediate_size,
+                   num_hidden_layers=dims.lm.num_hidden_layers, num_attention_heads=dims.lm.num_attention_heads,
+                   vocab_size=dims.lm.vocab_size, rms_norm_eps=dims.lm.rms_norm_eps, rope_theta=dims.lm.rope_theta,
+                   max_position_embeddings=dims.lm.max_position_embeddings, pad_token_id=dims.tok.pad,
+                   bos_token_id=dims.tok.bos, eos_token_id=dims.tok.eos,
+                   point_bert=dict(trans_dim=pb.trans_dim, depth=pb.depth, num_heads=pb.num_heads, group_size=pb.group_size,
+                                   num_group=pb.num_group, encoder_dims=pb.encoder_dims,
+                                   projection_hidden_dim=list(pb.projection_hidden_dim), npoints=pb.npoints))
+
+    def to_dims(self) -> EgoDims:
+        pbk = dict(self.point_bert or {})
+        pb = PointBertDims(point_dims=6 if self.use_color else 3, **pbk)
+        lm = LlamaDims(hidden_size=self.hidden_size, intermediate_size=self.intermediate_size,
+                       num_hidden_layers=self.num_hidden_layers, num_attention_heads=self.num_attention_heads,
+                       vocab_size=self.vocab_size, rms_norm_eps=self.rms_norm_eps,
+                       rope_theta=getattr(self, "rope_theta", 10000.0), max_position_embeddings=self.max_position_embeddings)
+        return EgoDims(pb=pb, lm=lm, tok=SpecialTokens(pad=self.pad_token_id or 0, bos=self.bos_token_id, eos=self.eos_token_id))
+
+
+@dataclass
+class CausalLMOutput:
+    """Same fields the reference reads from CausalLMOutputWithPast (train.py:174, evaluate.py)."""
+    logits: torch.Tensor
+    loss: Optional[torch.Tensor] = None
+    past_key_values: Optional[object] = None
+    hidden_states: Optional[object] = None
+    attentions: Optional[object] = None
+
+    def __getitem__(self, i):
+        return (self.logits,)[i]
+
+
+@dataclass
+class GenerateOutput:
+    sequences: torch.Tensor
+    scores: Tuple[torch.Tensor, ...]
+
+
+def _install(root: nn.Module, dotted: str, tensor: torch.Tensor, buffer: bool):
+    parts = dotted.split(".")
+    m = root
+    for p in parts[:-1]:
+        if not hasattr(m, p):
+            m.add_module(p, nn.Module())
+        m = getattr(m, p)
+    if buffer:
+        m.register_buffer(parts[-1], tensor)
+    else:
+        m.register_parameter(parts[-1], nn.Parameter(tensor, requires_grad=False))
+
+
+_BUFFER_LEAVES = ("running_mean", "running_var", "num_batches_tracked")
+
+
+class _LogitsFn(torch.autograd.Function):
+    """Bridges the engine into torch.autograd so `loss.backward()` of the reference's training loop
+    (train.py:176-183) drives the hand-written backward."""
+
+    @staticmethod
+    def forward(ctx, anchor, model, input_ids, attention_mask, point_clouds, fps_start, save):
+        eng = model.engine
+        hn = eng.forward_hidden(input_ids, attention_mask, point_clouds, fps_start, save=save)
+        logits = eng.logits(hn)
+        ctx.model, ctx.hn, ctx.saved = model, hn, save
+        B, S = input_ids.shape
+        return logits.view(B, S, -1)
+
+    @staticmethod
+    def backward(ctx, d_logits):
+        model = ctx.model
+        if not ctx.saved:
+            raise RuntimeError("backward through a forward that ran without grad")
+        eng = model.engine
+        model._begin_backward()
+        dl = d_logits.reshape(-1, d_logits.shape[-1])
+        if dl.dtype != eng.dtype or not dl.is_contiguous():
+            dl = dl.to(eng.dtype).contiguous()
+        d_hn = eng.backward_logits(dl, ctx.hn)
+        eng.backward_hidden(d_hn)
+        model._publish_grads()
+        return (torch.zeros_like(model._anchor), None, None, None, None, None, None)
+
+
+class TrajPointLLMForCausalLM(nn.Module):
+    def __init__(self, args, config, model_name: Optional[str] = None, device=None, dtype=torch.float32):
+        super().__init__()
+        self.args, self.config, self.model_name = args, config, model_name
+        self.dims = config.to_dims() if not isinstance(config, EgoDims) else config
+        dev = torch.device(device or "cuda")
+        if dev.type != "cuda":
+            raise RuntimeError("TrajPointLLMForCausalLM (egoscaler_amd) runs on an MI355X only; there is no CPU path")
+        for k, shape in synth.param_shapes(self.dims):
+            leaf = k.rsplit(".", 1)[-1]
+            is_buf = leaf in _BUFFER_LEAVES
+            t = torch.zeros(shape, dtype=torch.long if leaf == "num_batches_tracked" else dtype, device=dev)
+            _install(self, k, t, is_buf)
+        self._anchor = torch.zeros((), device=dev, requires_grad=True)
+        self.training_graph = True
+        self.accumulate_grads = False
+        self._tensors = None
+        self.engine = None
+        self.point_backbone_config = None
+        self._build_engine()
+        if model_name is not None and os.path.isdir(model_name):
+            self.load_pretrained_weights()
+        self._configure_trainable_parameters()
+
+    # -- plumbing ---------------------------------------------------------------------------------
+    def _build_engine(self):
+        tensors = {k: v for k, v in self.named_parameters()}
+        tensors.update({k: v for k, v in self.named_buffers()})
+        dtype = self.model.embed_tokens.weight.dtype
+        dev = self.model.embed_tokens.weight.device
+        old = self.engine
+        self.engine = Engine(self.dims, {k: v.data for k, v in tensors.items()}, dev, dtype)
+        if old is not None:
+            self.engine.trainable = old.trainable
+        pb = self.dims.pb
+        cfg = self.point_backbone_config or {}
+        cfg.update({"point_cloud_dim": pb.point_dims, "backbone_output_dim": pb.trans_dim,
+                    "project_output_dim": self.dims.lm.hidden_size, "point_token_len": pb.point_token_len,
+                    "mm_use_point_start_end": True, "projection_hidden_layer": len(pb.projection_hidden_dim),
+                    "projection_hidden_dim": list(pb.projection_hidden_dim), "use_max_pool": False})     # pointllm.py:49-59
+        self.point_backbone_config = cfg
+        self.model.point_backbone_config = cfg
+
+    def get_model(self):
+        return self.model
+
+    def _apply(self, fn, *a, **k):
+        r = super()._apply(fn, *a, **k)
+        if getattr(self, "engine", None) is not None:
+            self._build_engine()
+        return r
+
+    def load_state_dict(self, sd, strict=True, **kw):
+        r = super().load_state_dict(sd, strict=strict, **kw)
+        self.engine.prepared = False
+        return r
+
+    def load_pretrained_weights(self):
+        """HF directory: *.safetensors shards or pytorch_model*.bin (model_arch.py:25-31)."""
+        files = sorted(f for f in os.listdir(self.model_name) if f.endswith(".safetensors"))
+        sd = {}
+        if files:
+            from safetensors.torch import load_file
+            for f in files:
+                sd.update(load_file(os.path.join(self.model_name, f)))
+        else:
+            for f in sorted(f for f in os.listdir(self.model_name) if f.startswith("pytorch_model") and f.endswith(".bin")):
+                sd.update(torch.load(os.path.join(self.model_name, f), map_location="cpu", weights_only=True))
+        if sd:
+            self.load_state_dict(sd, strict=False)
+
+    def save_pretrained(self, path):
+        from safetensors.torch import save_file
+        if isinstance(self.config, PointLLMConfig):
+            self.config.save_pretrained(path)
+        os.makedirs(path, exist_ok=True)
+        save_file({k: v.detach().cpu().contiguous() for k, v in self.state_dict().items()}, os.path.join(path, "model.safetensors"))
+
+    def _configure_trainable_parameters(self):
+        """model_arch.py:33-51: point backbone frozen unless --unfreeze_pc_encoder; model.layers
+        frozen unless --unfreeze_language_model; embed_tokens always trainable; everything else
+        (point_proj, model.norm, lm_head) keeps requires_grad=True."""
+        if getattr(self.args, "unfreeze_pc_encoder", False):
+            raise NotImplementedError("--unfreeze_pc_encoder (PointBERT backward) is not built yet")
+        unfreeze_llm = bool(getattr(self.args, "unfreeze_language_model", False))
+        names = []
+        for n, p in self.named_parameters():
+            if n.startswith("model.point_backbone."):
+                p.requires_grad = False
+            elif n.startswith("model.layers."):
+                p.requires_grad = unfreeze_llm
+            else:
+                p.requires_grad = True
+            if p.requires_grad:
+                names.append(n)
+        self.engine.set_trainable(names)
+
+    def resize_token_embeddings(self, new_num_tokens, mean_resizing=False):
+        """builder.py:44: grow embed_tokens / lm_head; new rows N(0, 0.02) like HF with
+        mean_resizing=False (std = initializer_range)."""
+        old = self.dims.lm.vocab_size
+        if new_num_tokens == old:
+            return
+        for name in ("model.embed_tokens.weight", "lm_head.weight"):
+            mod, leaf = self, name
+            parts = name.split(".")
+            for q in parts[:-1]:
+                mod = getattr(mod, q)
+            w = getattr(mod, parts[-1])
+            nw = torch.empty(new_num_tokens, w.shape[1], dtype=w.dtype, device=w.device)
+            n = min(old, new_num_tokens)
+            nw[:n] = w.data[:n]
+            if new_num_tokens > old:
+                nw[old:].normal_(0.0, 0.02)
+            mod.register_parameter(parts[-1], nn.Parameter(nw, requires_grad=w.requires_grad))
+        self.dims.lm.vocab_size = new_num_tokens
+        if hasattr(self.config, "vocab_size"):
+            self.config.vocab_size = new_num_tokens
+        tr = self.engine.trainable
+        self.engine = None
+        self._build_engine()
+        self.engine.trainable = tr
+        self.engine.main_grad = {}
+
+    def initialize_tokenizer_point_backbone_config_wo_embedding(self, tokenizer):
+        """pointllm.py:277-300."""
+        cfg = self.point_backbone_config
+        pp = getattr(self.config, "DEFAULT_POINT_PATCH_TOKEN", "<point_patch>")
+        tokenizer.add_tokens([pp], special_tokens=True)
+        cfg["default_point_patch_token"] = pp
+        cfg["point_patch_token"] = tokenizer.convert_tokens_to_ids([pp])[0]
+        ps = getattr(self.config, "DEFAULT_POINT_START_TOKEN", "<point_start>")
+        pe = getattr(self.config, "DEFAULT_POINT_END_TOKEN", "<point_end>")
+        tokenizer.add_tokens([ps, pe], special_tokens=True)
+        cfg["default_point_start_token"], cfg["default_point_end_token"] = ps, pe
+        cfg["point_start_token"] = tokenizer.convert_tokens_to_ids([ps])[0]
+        cfg["point_end_token"] = tokenizer.convert_tokens_to_ids([pe])[0]
+        self.set_point_token_ids(cfg["point_patch_token"], cfg["point_start_token"], cfg["point_end_token"])
+
+    def set_point_token_ids(self, patch, start, end):
+        t = self.dims.tok
+        t.point_patch, t.point_start, t.point_end = int(patch), int(start), int(end)
+        self.point_backbone_config.update(point_patch_token=int(patch), point_start_token=int(start), point_end_token=int(end))
+
+    # -- gradients ----------------------------------------------------------------------------------
+    def _begin_backward(self):
+        eng = self.engine
+        for n, p in self.named_parameters():
+            if n in eng.trainable:
+                g = eng.grad_buffer(n)
+                fresh = (p.grad is None) if p.dtype == torch.float32 else (not self.accumulate_grads)
+                if fresh:
+                    g.zero_()
+
+    def _publish_grads(self):
+        eng = self.engine
+        for n, p in self.named_parameters():
+            if n in eng.trainable:
+                g = eng.main_grad[n]
+                p.main_grad = g
+                if p.dtype == torch.float32:
+                    p.grad = g
+
+    # -- reference API --------------------------------------------------------------------------------
+    def forward(self, input_ids=None, attention_mask=None, past_key_values=None, inputs_embeds=None, labels=None,
+                use_cache=None, output_attentions=None, output_hidden_states=None, point_clouds=None, return_dict=None,
+                fps_start=None):
+        """model_arch.py:53-75: only input_ids / attention_mask / point_clouds / return_dict are used."""
+        dev = self.engine.device
+        input_ids = input_ids.to(dev)
+        if fps_start is None and point_clouds is not None:
+            n = point_clouds[0].shape[0] if isinstance(point_clouds, (list, tuple)) else point_clouds.shape[1]
+            b = len(point_clouds) if isinstance(point_clouds, (list, tuple)) else point_clouds.shape[0]
+            fps_start = torch.randint(0, n, (b,), dtype=torch.long)            # misc.py:52 (global CPU RNG)
+        save = torch.is_grad_enabled() and self.training_graph
+        logits = _LogitsFn.apply(self._anchor, self, input_ids, attention_mask, point_clouds, fps_start, save)
+        out = CausalLMOutput(logits=logits)
+        return out if (return_dict is None or return_dict) else (logits,)
+
+    def loss_and_backward(self, input_ids, attention_mask, point_clouds, prompt_len, pad_token_id, fps_start=None,
+                          backward=True, grad_scale=1.0):
+        """Fused training step of train.py:166-183: forward, lm_head restricted to the trajectory span
+        [Lp-1, S-1), cross-entropy with ignore_index=pad (mean), and the full backward, without
+        materialising [B,S,V] logits.  Returns the loss (fp32 scalar tensor)."""
+        eng = self.engine
+        dev = eng.device
+        input_ids = input_ids.to(dev)
+        B, S = input_ids.shape
+        if fps_start is None and point_clouds is not None:
+            fps_start = torch.randint(0, point_clouds.shape[1], (B,), dtype=torch.long)
+        hn = eng.forward_hidden(input_ids, attention_mask, point_clouds, fps_start, save=backward)
+        d = hn.shape[1]
+        Lp = int(prompt_len)
+        hs = hn.view(B, S, d)[:, Lp - 1:S - 1].reshape(-1, d)
+        tg = input_ids[:, Lp:].reshape(-1).contiguous()
+        lg = eng.logits(hs)
+        ls, cnt = ops.cross_entropy(lg, tg, pad_token_id, dlogits=lg if backward else None, grad_scale=grad_scale)
+        loss = ls / cnt.float()
+        if backward:
+            self._begin_backward()
+            d_hs = eng.backward_logits(lg, hs)
+            d_hn = eng.ws.get("d_hn_full", (B, S, d), eng.dtype, zero=True)
+            d_hn[:, Lp - 1:S - 1] = d_hs.view(B, S - Lp, d)
+            eng.backward_hidden(d_hn.view(B * S, d))
+            self._publish_grads()
+        return loss[0]
+
+    @torch.no_grad()
+    def generate(self, input_ids=None, attention_mask=None, point_clouds=None, max_length=20, temperature=1.0, top_k=50,
+                 top_p=0.95, repetition_penalty=1.0, do_sample=True, num_return_sequences=1, fps_start=None,
+                 eos_token_id=None, pad_token_id=None, **kwargs):
+        """model_arch.py:77-108: `max_length` means max_new_tokens; returns .sequences [B,S0+T] and
+        .scores (T x [B,V]).  Prefill runs encoder + splice and fills the KV cache; every later step
+        feeds one token (the behaviour pointllm.py:112,255-275 intends; see DESIGN.md on the
+        reference's cache bug).  do_sample=False is greedy arg-max and is what parity pins."""
+        if num_return_sequences != 1 or repetition_penalty != 1.0:
+            raise NotImplementedError("num_return_sequences != 1 / repetition_penalty are not built")
+        eng = self.engine
+        dev = eng.device
+        ids = input_ids.to(dev)
+        B, S0 = ids.shape
+        mask = torch.ones(B, S0, dtype=torch.bool, device=dev) if attention_mask is None else attention_mask.to(dev).bool()
+        if fps_start is None and point_clouds is not None:
+            fps_start = torch.randint(0, point_clouds.shape[1], (B,), dtype=torch.long)
+        T = int(max_length)
+        cache = eng.new_kv_cache(B, S0 + T)
+        full_mask = torch.cat([mask, torch.ones(B, T, dtype=torch.bool, device=dev)], 1)
+        hn = eng.forward_hidden(ids, full_mask[:, :S0], point_clouds, fps_start, save=False, kv_cache=cache)
+        d = hn.shape[1]
+        last = hn.view(B, S0, d)[:, -1].contiguous()
+        seq, scores = ids, []
+        done = torch.zeros(B, dtype=torch.bool, device=dev)
+        for t in range(T):
+            lg = eng.logits(last).float()
+            if do_sample:
+                s = lg / max(float(temperature or 1.0), 1e-6)
+                if top_k:
+                    kth = torch.topk(s, min(int(top_k), s.shape[-1]), dim=-1)[0][:, -1:]
+                    s = s.masked_fill(s < kth, float("-inf"))
+                if top_p and top_p < 1.0:
+                    sv, si = torch.sort(s, descending=False, dim=-1)
+                    cp = sv.softmax(-1).cumsum(-1)
+                    rm = cp <= (1 - top_p)
+                    rm[:, -1:] = False
+                    s = s.masked_fill(rm.scatter(1, si, rm), float("-inf"))
+                scores.append(s)
+                nxt = torch.multinomial(s.softmax(-1), 1)
+            else:
+                scores.append(lg)
+                nxt = lg.argmax(-1, keepdim=True)
+            if eos_token_id is not None:
+                nxt = torch.where(done[:, None], torch.full_like(nxt, pad_token_id if pad_token_id is not None else eos_token_id), nxt)
+                done = done | (nxt[:, 0] == eos_token_id)
+            seq = torch.cat([seq, nxt], 1)
+            if t + 1 == T or (eos_token_id is not None and bool(done.all())):
+                break
+            last = eng.forward_hidden(nxt, full_mask[:, :S0 + t + 1], None, None, save=False, kv_cache=cache)
+        return GenerateOutput(sequences=seq, scores=tuple(scores))
+
+    def train(self, mode: bool = True):
+        """model_arch.py:110-124: frozen parts stay in eval(); embed_tokens follows `mode`."""
+        super().train(mode)
+        if not getattr(self.args, "unfreeze_language_model", False):
+            self.model.layers.eval()
+            self.model.embed_tokens.train(mode)
+        if not getattr(self.args, "unfreeze_pc_encoder", False):
+            self.model.point_backbone.eval()
+        return self
