@@ -1,0 +1,248 @@
+#!/usr/bin/env python3
+"""bench.py — clips/sec/GPU of the EgoScaler trajectory-generator training step on MI355X.
+
+One step = one pass of the hot path over one batch of synthetic input already resident in HBM:
+  A1 un-project 8 RGB-D frames/sample -> A2 pc_norm -> A3-A8 PointBERT -> A9 projector -> A10 splice
+  -> A11 32 LLaMA-7B layers -> A12 lm_head + CE on the trajectory span -> full backward -> (N>1: RCCL
+  gradient all-reduce, overlapped) -> AdamW step.
+Config = BASELINE.json configs[1]: bs=8 per GPU, 8-frame 224x224 clips, 16-token text, bf16.
+
+  python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
+Prints ONE JSON line on rank 0 (contract in the task statement), with `roofline` for the dominant
+kernel (the MFMA GEMM) from HIP events recorded in the timed region, and `cpu_baseline` (the CPU
+oracle timed on this box's host cores; rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+import types
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA (MI355X_MICROARCH.md, chip-level parameters)
+
+
+def flops_per_sample(dims, S, S_traj, frozen_llm=True):
+    """Algorithmic FLOPs per sample (SURVEY.md §8d 'Roofline - dense part')."""
+    lm, pb = dims.lm, dims.pb
+    d, f, L, V = lm.hidden_size, lm.intermediate_size, lm.num_hidden_layers, lm.vocab_size
+    G, K, D, P = pb.num_group, pb.group_size, pb.trans_dim, pb.point_token_len
+    pointnet = 2 * G * K * (pb.point_dims * pb.pn_c1 + pb.pn_c1 * pb.pn_c2 + 2 * pb.pn_c2 * pb.pn_c3 + pb.pn_c3 * pb.encoder_dims)
+    blk = 2 * P * (3 * D * D + D * D + 2 * pb.mlp_ratio * D * D) + 4 * P * P * D
+    pointbert = pb.depth * blk + 2 * G * pb.encoder_dims * D
+    dims_p = [D] + list(pb.projection_hidden_dim) + [d]
+    proj = sum(2 * P * a * b for a, b in zip(dims_p[:-1], dims_p[1:]))
+    lin = L * 2 * S * (4 * d * d + 3 * d * f)
+    attn = L * 4 * S * S * d // 2
+    head = 2 * d * V * S_traj
+    fwd_front = pointnet + pointbert + proj
+    fwd_llm = lin + attn + head
+    bwd = (fwd_llm if frozen_llm else 2 * fwd_llm) + 2 * proj      # dgrad only through a frozen LLM; frozen encoder has no backward
+    return {"fwd": fwd_front + fwd_llm, "fwd_bwd": fwd_front + fwd_llm + bwd}
+
+
+def cpu_baseline(dims, Lp, threads):
+    """Oracle (CPU restatement of the reference) on a bounded sample: ONE clip, full PointBERT +
+    projector + splice + lm_head/CE, with 1 and 2 LLaMA layers at 7B width, fp32, forward+backward
+    (frozen-LLM mode).  Per-layer time = t(2)-t(1); whole model = t(1) + 31*(t(2)-t(1))."""
+    import copy
+    from egoscaler_amd import synth
+    from oracle import pointllm as OPL, llama as OL, pointcloud as OPC
+    torch.set_num_threads(threads)
+    rgb, depth = synth.synth_clip(0, 8, 224, 224)
+    f, pp = synth.clip_intrinsics(224)
+    t0 = time.time()
+    pc = torch.from_numpy(OPC.clip_to_cloud(rgb, depth, pp, f, synth.DEPTH_THRESHOLD, dims.pb.npoints))[None]
+    t_front = time.time() - t0
+    toks, masks, _ = synth.synth_batch(dims, 1)
+    times = {}
+    for L in (1, 2):
+        dd = copy.deepcopy(dims)
+        dd.lm.num_hidden_layers = L
+        g = torch.Generator().manual_seed(0)
+        sd = {}
+        for k, shp in synth.param_shapes(dd):
+            leaf = k.rsplit(".", 1)[-1]
+            if leaf == "num_batches_tracked":
+                sd[k] = torch.zeros((), dtype=torch.long)
+            elif leaf == "running_var" or (leaf == "weight" and len(shp) == 1):
+                sd[k] = torch.ones(shp)
+            else:
+                sd[k] = torch.randn(shp, generator=g) * 0.02
+        train = lambda k: not (k.startswith("model.layers.") or k.startswith("model.point_backbone."))
+        sd = {k: v.requires_grad_(v.dtype.is_floating_point and train(k)) for k, v in sd.items()}
+        t0 = time.time()
+        logits = OPL.forward(sd, dd, toks, masks, pc, np.array([0]))
+        loss = OL.traj_loss(logits, toks, Lp, dd.tok.pad)
+        loss.backward()
+        times[L] = time.time() - t0
+        del sd, logits, loss
+    per_layer = max(times[2] - times[1], 1e-6)
+    total = t_front + times[1] + (dims.lm.num_hidden_layers - 1) * per_layer
+    return {"value": 1.0 / total, "unit": "clips/s", "cores": threads, "kind": "port",
+            "sample": (f"1 clip (8x224x224) fwd+bwd fp32, frozen-LLM mode, oracle on {threads} threads: un-projection+pc_norm "
+                       f"{t_front:.2f}s, PointBERT+projector+1 LLaMA-7B layer+lm_head/CE {times[1]:.2f}s, extra layer {per_layer:.2f}s; "
+                       f"32-layer time extrapolated linearly = {total:.1f}s")}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--mode", default="frozen", choices=["frozen", "unfrozen"], help="reference default flags freeze the LLM (model_arch.py:33-51)")
+    ap.add_argument("--layers", type=int, default=None, help="debug only: fewer LLaMA layers (result is then marked invalid)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gemm-events", action="store_true")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    if world != a.gpus and world > 1:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from egoscaler_amd import ops, synth
+    from egoscaler_amd.config import dims_7b
+    from egoscaler_amd.dp import GradSync
+    from egoscaler_amd.optim import EgoAdamW
+    from egoscaler_amd.pointllm import TrajPointLLMForCausalLM
+
+    dims = dims_7b()
+    if a.layers is not None:
+        dims.lm.num_hidden_layers = a.layers
+    B, T, H, W = a.batch, 8, 224, 224
+    margs = types.SimpleNamespace(unfreeze_pc_encoder=False, unfreeze_language_model=(a.mode == "unfrozen"), num_bins=256, model_name=None)
+    model = TrajPointLLMForCausalLM(margs, dims, None, device=dev, dtype=torch.bfloat16)
+    g = torch.Generator(device=dev).manual_seed(1234)          # same weights on every rank
+    with torch.no_grad():
+        for n, p in list(model.named_parameters()) + list(model.named_buffers()):
+            leaf = n.rsplit(".", 1)[-1]
+            if leaf == "num_batches_tracked":
+                continue
+            if leaf == "running_var" or (leaf == "weight" and p.dim() == 1):
+                p.fill_(1.0)
+            elif leaf == "running_mean":
+                p.zero_()
+            else:
+                fan_in = p[0].numel() if p.dim() > 1 else p.numel()
+                std = 0.02 if fan_in >= 1024 else min(0.35, fan_in ** -0.5)
+                tmp = torch.empty(p.shape, dtype=torch.float32, device=dev).normal_(0, std, generator=g) if p.numel() < (1 << 28) else None
+                if tmp is not None:
+                    p.copy_(tmp)
+                else:
+                    for r0 in range(0, p.shape[0], 4096):
+                        blk = p[r0:r0 + 4096]
+                        blk.copy_(torch.empty(blk.shape, dtype=torch.float32, device=dev).normal_(0, std, generator=g))
+    model.engine.prepared = False
+    model.train()
+    opt = EgoAdamW(model, lr=2e-5)
+    sync = GradSync() if world > 1 else None
+    model.engine.grad_sync = sync
+
+    # ---- synthetic batch, resident in HBM before the timed region (rank r gets samples r*B .. r*B+B-1)
+    clips = [synth.synth_clip(rank * B + i, T, H, W) for i in range(B)]
+    rgb = torch.from_numpy(np.stack([c[0] for c in clips])).to(dev)
+    depth = torch.from_numpy(np.stack([c[1] for c in clips])).to(dev)
+    toks, masks, Lp = synth.synth_batch(dims, B, text_len=16, num_steps=20, max_traj_token=160, first_id=rank * B)
+    toks, masks = toks.to(dev), masks.to(dev)
+    S = toks.shape[1]
+    fx, pp = synth.clip_intrinsics(H)
+    fps_start = torch.zeros(B, dtype=torch.int32, device=dev)
+    N = dims.pb.npoints
+
+    def step(check=False):
+        pts, col, cnt = ops.unproject_gather(rgb, depth, pp, fx, fx, synth.DEPTH_THRESHOLD, n_out=N)        # A1
+        if check and int(cnt.min()) < N:
+            raise RuntimeError("synthetic clip has too few valid pixels")
+        pc = ops.pc_norm(pts, col)                                                                            # A2
+        loss = model.loss_and_backward(toks, masks, pc, Lp, dims.tok.pad, fps_start=fps_start)                # A3-A15
+        if sync is not None:
+            sync.finish()
+        opt.step(grad_scale=sync.grad_scale if sync is not None else 1.0)
+        return loss
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    loss0 = None
+    for i in range(a.warmup):
+        loss0 = step(check=(i == 0))
+    torch.cuda.synchronize()
+    prof = None
+    if not a.no_gemm_events:
+        prof = ops.GemmProfiler(min_flops=1e9)
+        ops.PROFILER = prof
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    barrier()
+    dt = time.perf_counter() - t0
+    ops.PROFILER = None
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax)
+    clips_total = a.steps * B * world
+    value = clips_total / dt / world            # clips/sec/GPU ... see `value` note below
+
+    fl = flops_per_sample(dims, S, S - Lp, frozen_llm=(a.mode == "frozen"))
+    roof = None
+    if prof is not None:
+        sm = prof.summary()
+        ach = sm["flops"] / (sm["ms"] * 1e-3) / 1e12 if sm["ms"] > 0 else 0.0
+        traffic = None
+        pj = os.path.join(ROOT, "profiles", "pmc_gemm_latest.json")
+        if os.path.exists(pj):
+            try:
+                traffic = json.load(open(pj)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        roof = {"bound": "mfma", "kernel": "egomi_gemm (all launches >= 1 GFLOP)", "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS,
+                "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
+                "launches_per_step": sm["launches"] // max(1, a.steps), "avg_launch_ms": round(sm["ms"] / max(1, sm["launches"]), 4),
+                "gemm_share_of_step": round(sm["ms"] / (dt * 1e3), 3)}
+    out = {
+        "metric": "clips/sec/GPU (8-frame 224^2, 16-token text) fwd+bwd",
+        "value": round(clips_total / dt, 4), "unit": "clips/s",
+        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": "configs[1]: bs=8/GPU, 8-frame 224x224 RGB-D clip -> 8192-pt cloud, 16-token text, S=%d, PointBERT-v1.2 + LLaMA-7B shapes, "
+                               "fwd+bwd+AdamW, %s-LLM mode (reference default flags)" % (S, a.mode),
+                   "global_batch": B * world, "seq_len": S, "parallelism": f"dp{world}", "per_gpu_clips_per_s": round(value, 4),
+                   "algorithmic_tflop_per_clip": round(fl["fwd_bwd"] / 1e12, 3),
+                   "model_tflops_per_gpu": round(fl["fwd_bwd"] * value / 1e12, 2), "loss": round(float(loss), 4),
+                   "valid": a.layers is None and B == 8},
+    }
+    if roof is not None:
+        out["roofline"] = roof
+    if rank == 0:
+        if world == 1 and not a.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(dims_7b(), Lp, min(16, os.cpu_count() or 1))
+            except Exception as e:      # the oracle is a reported baseline; never fail the bench on it
+                out["cpu_baseline"] = {"value": None, "unit": "clips/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -6,6 +6,11 @@ op in egoscaler_amd.ops raises with it.  Nothing here imports oracle/.
 import ctypes
 import os
 
+# torch must be imported BEFORE libegomi.so is dlopen'ed: the PyTorch-ROCm wheel carries its own
+# libamdhip64; loading ours first would bring a second HIP runtime into the process (the system
+# one), and launches through it fail with "no ROCm-capable device is detected".
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libegomi.so")
 _lib = None
@@ -31,6 +36,7 @@ def lib():
         _lib = ctypes.CDLL(LIB_PATH)
         _lib.egomi_strerror.restype = ctypes.c_char_p
         _lib.egomi_strerror.argtypes = [c_i]
+        _lib.egomi_last_launch_error.restype = ctypes.c_char_p
         _lib.egomi_unproject_workspace_bytes.restype = c_sz
         _lib.egomi_unproject_workspace_bytes.argtypes = [c_i] * 4
     return _lib
@@ -39,6 +45,8 @@ def lib():
 def check(rc: int, what: str):
     if rc != 0:
         msg = lib().egomi_strerror(rc).decode()
+        if rc == -3:
+            msg += ": " + lib().egomi_last_launch_error().decode()
         raise EgomiError(f"{what}: egomi error {rc} ({msg})")
 
 

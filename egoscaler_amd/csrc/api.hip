@@ -1,7 +1,12 @@
 // Library identity + error strings.
 #include "common.h"
 
+thread_local int egomi_launch_err_ = 0;
+thread_local int egomi_last_hip_error_ = 0;
+
 extern "C" int egomi_version(void) { return 100; }
+
+extern "C" const char* egomi_last_launch_error(void) { return hipGetErrorString((hipError_t)egomi_last_hip_error_); }
 
 extern "C" const char* egomi_strerror(int code) {
     switch (code) {

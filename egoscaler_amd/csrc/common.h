@@ -101,9 +101,21 @@ __device__ __forceinline__ float act_apply(float x, int act) {
     return x;
 }
 
+// hipGetLastError() also reports benign leftovers of the caller's own HIP use (e.g. hipErrorNotReady
+// from an event query in torch's allocator), so every launch clears it first and records its own.
+extern thread_local int egomi_launch_err_;      // defined in api.hip
+extern thread_local int egomi_last_hip_error_;
+#define EGOMI_LAUNCH(...)                                              \
+    do {                                                               \
+        (void)hipGetLastError();                                       \
+        hipLaunchKernelGGL(__VA_ARGS__);                               \
+        const hipError_t e_ = hipGetLastError();                       \
+        if (e_ != hipSuccess) { egomi_launch_err_ = 1; egomi_last_hip_error_ = (int)e_; } \
+    } while (0)
 static inline int egomi_launch_status() {
-    hipError_t e = hipGetLastError();
-    return e == hipSuccess ? EGOMI_OK : EGOMI_E_LAUNCH;
+    const int e = egomi_launch_err_;
+    egomi_launch_err_ = 0;
+    return e ? EGOMI_E_LAUNCH : EGOMI_OK;
 }
 
 #define EGOMI_DISPATCH_DTYPE(dtype, ...)                         \

@@ -45,7 +45,7 @@ extern "C" int egomi_layernorm_fwd(const void* x, const void* add, const void* w
                                    int rows, int cols, float eps, int dtype, egomi_stream_t stream) {
     if (!x || !w || !b || !y) return EGOMI_E_BADARG;
     if (rows <= 0 || cols <= 0) return EGOMI_E_SHAPE;
-    EGOMI_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(layernorm_fwd_kernel<T>, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream,
+    EGOMI_DISPATCH_DTYPE(dtype, EGOMI_LAUNCH(layernorm_fwd_kernel<T>, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream,
                                                    (const T*)x, (const T*)add, (const T*)w, (const T*)b, (T*)sum_out, (T*)y, rows, cols, eps));
     return egomi_launch_status();
 }
@@ -145,7 +145,7 @@ extern "C" int egomi_rmsnorm_fwd(const void* x, const void* w, void* y, float* r
                                  egomi_stream_t stream) {
     if (!x || !w || !y) return EGOMI_E_BADARG;
     if (rows <= 0 || cols <= 0 || cols % 8) return EGOMI_E_SHAPE;
-    EGOMI_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(rmsnorm_fwd_kernel<T>, dim3(rows), dim3(256), 0, (hipStream_t)stream,
+    EGOMI_DISPATCH_DTYPE(dtype, EGOMI_LAUNCH(rmsnorm_fwd_kernel<T>, dim3(rows), dim3(256), 0, (hipStream_t)stream,
                                                    (const T*)x, (const T*)w, (T*)y, rstd, cols, eps));
     return egomi_launch_status();
 }
@@ -156,7 +156,7 @@ extern "C" int egomi_rmsnorm_bwd(const void* dy, const void* x, const void* w, c
     if (rows <= 0 || cols <= 0 || cols % 8) return EGOMI_E_SHAPE;
     if (cols > 8192) return EGOMI_E_UNSUPPORTED;
     const int grid = rows < 1024 ? rows : 1024;
-    EGOMI_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(rmsnorm_bwd_kernel<T>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
+    EGOMI_DISPATCH_DTYPE(dtype, EGOMI_LAUNCH(rmsnorm_bwd_kernel<T>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
                                                    (const T*)dy, (const T*)x, (const T*)w, rstd, (T*)dx, (const T*)dx_add, dw, rows, cols));
     return egomi_launch_status();
 }
@@ -200,7 +200,7 @@ extern "C" int egomi_rope(void* x, const float* cos_tab, const float* sin_tab, i
     if (rows <= 0 || S <= 0 || H <= 0 || hd <= 0 || (hd & 1) || ld < (int64_t)H * hd || pos_offset < 0) return EGOMI_E_SHAPE;
     const long long total = rows * H * (hd / 2);
     const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
-    EGOMI_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(rope_kernel<T>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
+    EGOMI_DISPATCH_DTYPE(dtype, EGOMI_LAUNCH(rope_kernel<T>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
                                                    (T*)x, cos_tab, sin_tab, rows, S, pos_offset, H, hd, ld, inverse));
     return egomi_launch_status();
 }
@@ -259,7 +259,7 @@ extern "C" int egomi_swiglu_fwd(const void* gate, const void* up, void* out, int
                                 int dtype, egomi_stream_t stream) {
     if (!gate || !up || !out) return EGOMI_E_BADARG;
     if (rows <= 0 || cols <= 0 || cols % 8 || ld_in % 8 || ld_out % 8 || ld_in < cols || ld_out < cols) return EGOMI_E_SHAPE;
-    EGOMI_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(swiglu_fwd_kernel<T>, dim3(ew_grid(rows * (cols / 8))), dim3(256), 0, (hipStream_t)stream,
+    EGOMI_DISPATCH_DTYPE(dtype, EGOMI_LAUNCH(swiglu_fwd_kernel<T>, dim3(ew_grid(rows * (cols / 8))), dim3(256), 0, (hipStream_t)stream,
                                                    (const T*)gate, (const T*)up, (T*)out, rows, cols, ld_in, ld_out));
     return egomi_launch_status();
 }
@@ -268,7 +268,7 @@ extern "C" int egomi_swiglu_bwd(const void* dact, const void* gate, const void* 
                                 int64_t ld_in, int64_t ld_act, int64_t ld_out, int dtype, egomi_stream_t stream) {
     if (!dact || !gate || !up || !dgate || !dup) return EGOMI_E_BADARG;
     if (rows <= 0 || cols <= 0 || cols % 8 || ld_in % 8 || ld_act % 8 || ld_out % 8) return EGOMI_E_SHAPE;
-    EGOMI_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(swiglu_bwd_kernel<T>, dim3(ew_grid(rows * (cols / 8))), dim3(256), 0, (hipStream_t)stream,
+    EGOMI_DISPATCH_DTYPE(dtype, EGOMI_LAUNCH(swiglu_bwd_kernel<T>, dim3(ew_grid(rows * (cols / 8))), dim3(256), 0, (hipStream_t)stream,
                                                    (const T*)dact, (const T*)gate, (const T*)up, (T*)dgate, (T*)dup, rows, cols, ld_in, ld_act, ld_out));
     return egomi_launch_status();
 }
@@ -292,13 +292,13 @@ __global__ __launch_bounds__(256) void gelu_kernel(const T* x, const T* dy, T* o
 extern "C" int egomi_gelu_fwd(const void* x, void* y, int64_t n, int dtype, egomi_stream_t stream) {
     if (!x || !y) return EGOMI_E_BADARG;
     if (n <= 0) return EGOMI_E_SHAPE;
-    EGOMI_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(gelu_kernel<T>, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, (const T*)x, (const T*)nullptr, (T*)y, n));
+    EGOMI_DISPATCH_DTYPE(dtype, EGOMI_LAUNCH(gelu_kernel<T>, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, (const T*)x, (const T*)nullptr, (T*)y, n));
     return egomi_launch_status();
 }
 extern "C" int egomi_gelu_bwd(const void* dy, const void* x, void* dx, int64_t n, int dtype, egomi_stream_t stream) {
     if (!x || !dy || !dx) return EGOMI_E_BADARG;
     if (n <= 0) return EGOMI_E_SHAPE;
-    EGOMI_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(gelu_kernel<T>, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, (const T*)x, (const T*)dy, (T*)dx, n));
+    EGOMI_DISPATCH_DTYPE(dtype, EGOMI_LAUNCH(gelu_kernel<T>, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, (const T*)x, (const T*)dy, (T*)dx, n));
     return egomi_launch_status();
 }
 
@@ -369,7 +369,7 @@ extern "C" int egomi_softmax_fwd(const float* scores, int64_t ld_s, const uint8_
     if (Z <= 0 || heads <= 0 || Sq <= 0 || Sk <= 0 || ld_s < Sk || ld_p < Sk) return EGOMI_E_SHAPE;
     if (Sk > 2048) return EGOMI_E_UNSUPPORTED;
     const long long rows = (long long)Z * Sq;
-    EGOMI_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(softmax_fwd_kernel<T>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+    EGOMI_DISPATCH_DTYPE(dtype, EGOMI_LAUNCH(softmax_fwd_kernel<T>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
                                                    scores, key_mask, rows, heads, Sq, Sk, ld_s, causal, q_offset, (T*)P, ld_p));
     return egomi_launch_status();
 }
@@ -378,7 +378,7 @@ extern "C" int egomi_softmax_bwd(const void* P, int64_t ld_p, const float* dP, i
                                  int dtype, egomi_stream_t stream) {
     if (!P || !dP || !dS) return EGOMI_E_BADARG;
     if (rows <= 0 || Sk <= 0) return EGOMI_E_SHAPE;
-    EGOMI_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(softmax_bwd_kernel<T>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+    EGOMI_DISPATCH_DTYPE(dtype, EGOMI_LAUNCH(softmax_bwd_kernel<T>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
                                                    (const T*)P, ld_p, dP, ld_dp, (T*)dS, ld_ds, rows, Sk));
     return egomi_launch_status();
 }
@@ -423,7 +423,7 @@ extern "C" int egomi_splice_scan(const int64_t* ids, int B, int S, int64_t patch
                                  int32_t* start_pos, int32_t* err, egomi_stream_t stream) {
     if (!ids || !start_pos || !err) return EGOMI_E_BADARG;
     if (B <= 0 || S <= 0 || P <= 0) return EGOMI_E_SHAPE;
-    hipLaunchKernelGGL(splice_scan_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, ids, S, patch_id, start_id, end_id, P, start_pos, err);
+    EGOMI_LAUNCH(splice_scan_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, ids, S, patch_id, start_id, end_id, P, start_pos, err);
     return egomi_launch_status();
 }
 
@@ -475,7 +475,7 @@ extern "C" int egomi_embed_splice_fwd(const int64_t* ids, const void* W, const v
                                       int P, int V, void* out, int dtype, egomi_stream_t stream) {
     if (!ids || !W || !out) return EGOMI_E_BADARG;
     if (B <= 0 || S <= 0 || d <= 0 || d % 8 || V <= 0) return EGOMI_E_SHAPE;
-    EGOMI_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(embed_splice_fwd_kernel<T>, dim3(B * S), dim3(256), 0, (hipStream_t)stream,
+    EGOMI_DISPATCH_DTYPE(dtype, EGOMI_LAUNCH(embed_splice_fwd_kernel<T>, dim3(B * S), dim3(256), 0, (hipStream_t)stream,
                                                    ids, (const T*)W, (const T*)feats, start_pos, S, d, P, V, (T*)out));
     return egomi_launch_status();
 }
@@ -484,7 +484,7 @@ extern "C" int egomi_embed_splice_bwd(const void* dout, const int64_t* ids, cons
                                       float* dW, void* dfeats, int dtype, egomi_stream_t stream) {
     if (!dout || !ids) return EGOMI_E_BADARG;
     if (B <= 0 || S <= 0 || d <= 0 || d % 8 || V <= 0) return EGOMI_E_SHAPE;
-    EGOMI_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(embed_splice_bwd_kernel<T>, dim3(B * S), dim3(256), 0, (hipStream_t)stream,
+    EGOMI_DISPATCH_DTYPE(dtype, EGOMI_LAUNCH(embed_splice_bwd_kernel<T>, dim3(B * S), dim3(256), 0, (hipStream_t)stream,
                                                    (const T*)dout, ids, start_pos, S, d, P, V, dW, (T*)dfeats));
     return egomi_launch_status();
 }
@@ -536,7 +536,7 @@ __global__ __launch_bounds__(1024) void ce_fwd_bwd_kernel(const T* logits, long 
 extern "C" int egomi_ce_count(const int64_t* targets, int64_t n, int64_t ignore, int32_t* count, egomi_stream_t stream) {
     if (!targets || !count) return EGOMI_E_BADARG;
     if (n <= 0) return EGOMI_E_SHAPE;
-    hipLaunchKernelGGL(ce_count_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, targets, n, ignore, count);
+    EGOMI_LAUNCH(ce_count_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, targets, n, ignore, count);
     return egomi_launch_status();
 }
 
@@ -544,7 +544,7 @@ extern "C" int egomi_ce_fwd_bwd(const void* logits, int64_t ld, const int64_t* t
                                 float* loss_sum, void* dlogits, int64_t ldd, float grad_scale, int dtype, egomi_stream_t stream) {
     if (!logits || !targets || !count || !loss_sum) return EGOMI_E_BADARG;
     if (R <= 0 || V <= 0 || ld < V || (dlogits && ldd < V)) return EGOMI_E_SHAPE;
-    EGOMI_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(ce_fwd_bwd_kernel<T>, dim3(R), dim3(1024), 0, (hipStream_t)stream,
+    EGOMI_DISPATCH_DTYPE(dtype, EGOMI_LAUNCH(ce_fwd_bwd_kernel<T>, dim3(R), dim3(1024), 0, (hipStream_t)stream,
                                                    (const T*)logits, ld, targets, V, ignore, count, loss_sum, (T*)dlogits, ldd, grad_scale));
     return egomi_launch_status();
 }
@@ -574,10 +574,10 @@ extern "C" int egomi_adamw(float* master, void* model_copy, const float* grad, f
     if (n <= 0 || step <= 0) return EGOMI_E_SHAPE;
     const float bc1 = 1.0f - powf(beta1, (float)step), bc2s = sqrtf(1.0f - powf(beta2, (float)step));
     if (!model_copy || copy_dtype == EGOMI_F32)
-        hipLaunchKernelGGL(adamw_kernel<float>, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, master, (float*)model_copy, grad, m, v,
+        EGOMI_LAUNCH(adamw_kernel<float>, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, master, (float*)model_copy, grad, m, v,
                            (long long)n, lr, beta1, beta2, eps, weight_decay, bc1, bc2s, grad_scale);
     else if (copy_dtype == EGOMI_BF16)
-        hipLaunchKernelGGL(adamw_kernel<bf16_t>, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, master, (bf16_t*)model_copy, grad, m, v,
+        EGOMI_LAUNCH(adamw_kernel<bf16_t>, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, master, (bf16_t*)model_copy, grad, m, v,
                            (long long)n, lr, beta1, beta2, eps, weight_decay, bc1, bc2s, grad_scale);
     else return EGOMI_E_BADARG;
     return egomi_launch_status();
@@ -606,7 +606,7 @@ extern "C" int egomi_transpose(const void* in, int R, int C, int64_t ldi, void* 
     if (!in || !out) return EGOMI_E_BADARG;
     if (R <= 0 || C <= 0 || ldi < C || ldo < R) return EGOMI_E_SHAPE;
     dim3 grid((C + 31) / 32, (unsigned)((ldo + 31) / 32));
-    EGOMI_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(transpose_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, (const T*)in, R, C, ldi, (T*)out, ldo));
+    EGOMI_DISPATCH_DTYPE(dtype, EGOMI_LAUNCH(transpose_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, (const T*)in, R, C, ldi, (T*)out, ldo));
     return egomi_launch_status();
 }
 
@@ -619,10 +619,10 @@ extern "C" int egomi_cast(const void* in, int in_dtype, void* out, int out_dtype
     if (n <= 0) return EGOMI_E_SHAPE;
     hipStream_t s = (hipStream_t)stream;
     const dim3 g(ew_grid(n)), b(256);
-    if (in_dtype == EGOMI_F32 && out_dtype == EGOMI_BF16) hipLaunchKernelGGL((cast_kernel<float, bf16_t>), g, b, 0, s, (const float*)in, (bf16_t*)out, (long long)n);
-    else if (in_dtype == EGOMI_BF16 && out_dtype == EGOMI_F32) hipLaunchKernelGGL((cast_kernel<bf16_t, float>), g, b, 0, s, (const bf16_t*)in, (float*)out, (long long)n);
-    else if (in_dtype == EGOMI_F32 && out_dtype == EGOMI_F32) hipLaunchKernelGGL((cast_kernel<float, float>), g, b, 0, s, (const float*)in, (float*)out, (long long)n);
-    else if (in_dtype == EGOMI_BF16 && out_dtype == EGOMI_BF16) hipLaunchKernelGGL((cast_kernel<bf16_t, bf16_t>), g, b, 0, s, (const bf16_t*)in, (bf16_t*)out, (long long)n);
+    if (in_dtype == EGOMI_F32 && out_dtype == EGOMI_BF16) EGOMI_LAUNCH((cast_kernel<float, bf16_t>), g, b, 0, s, (const float*)in, (bf16_t*)out, (long long)n);
+    else if (in_dtype == EGOMI_BF16 && out_dtype == EGOMI_F32) EGOMI_LAUNCH((cast_kernel<bf16_t, float>), g, b, 0, s, (const bf16_t*)in, (float*)out, (long long)n);
+    else if (in_dtype == EGOMI_F32 && out_dtype == EGOMI_F32) EGOMI_LAUNCH((cast_kernel<float, float>), g, b, 0, s, (const float*)in, (float*)out, (long long)n);
+    else if (in_dtype == EGOMI_BF16 && out_dtype == EGOMI_BF16) EGOMI_LAUNCH((cast_kernel<bf16_t, bf16_t>), g, b, 0, s, (const bf16_t*)in, (bf16_t*)out, (long long)n);
     else return EGOMI_E_BADARG;
     return egomi_launch_status();
 }
@@ -635,7 +635,7 @@ __global__ __launch_bounds__(256) void add_kernel(const T* a, const T* b, T* out
 extern "C" int egomi_add(const void* a, const void* b, void* out, int64_t n, int dtype, egomi_stream_t stream) {
     if (!a || !b || !out) return EGOMI_E_BADARG;
     if (n <= 0) return EGOMI_E_SHAPE;
-    EGOMI_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(add_kernel<T>, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, (const T*)a, (const T*)b, (T*)out, (long long)n));
+    EGOMI_DISPATCH_DTYPE(dtype, EGOMI_LAUNCH(add_kernel<T>, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, (const T*)a, (const T*)b, (T*)out, (long long)n));
     return egomi_launch_status();
 }
 
@@ -664,7 +664,7 @@ __global__ __launch_bounds__(256) void group_max_kernel(const T* x, int M, int C
 extern "C" int egomi_group_max(const void* x, int BG, int M, int C, void* out, int concat, int dtype, egomi_stream_t stream) {
     if (!x || !out) return EGOMI_E_BADARG;
     if (BG <= 0 || M <= 0 || C <= 0) return EGOMI_E_SHAPE;
-    EGOMI_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(group_max_kernel<T>, dim3(BG), dim3(256), 0, (hipStream_t)stream, (const T*)x, M, C, (T*)out, concat));
+    EGOMI_DISPATCH_DTYPE(dtype, EGOMI_LAUNCH(group_max_kernel<T>, dim3(BG), dim3(256), 0, (hipStream_t)stream, (const T*)x, M, C, (T*)out, concat));
     return egomi_launch_status();
 }
 
@@ -690,11 +690,11 @@ extern "C" int egomi_linear_smallk(const void* x, int x_dtype, const void* w, co
     hipStream_t s = (hipStream_t)stream;
     const dim3 g(ew_grid(R * N)), bl(256);
     if (x_dtype == EGOMI_F32 && dtype == EGOMI_F32)
-        hipLaunchKernelGGL((linear_smallk_kernel<float, float>), g, bl, 0, s, (const float*)x, (const float*)w, (const float*)b, (float*)y, (long long)R, N, K, act);
+        EGOMI_LAUNCH((linear_smallk_kernel<float, float>), g, bl, 0, s, (const float*)x, (const float*)w, (const float*)b, (float*)y, (long long)R, N, K, act);
     else if (x_dtype == EGOMI_F32 && dtype == EGOMI_BF16)
-        hipLaunchKernelGGL((linear_smallk_kernel<float, bf16_t>), g, bl, 0, s, (const float*)x, (const bf16_t*)w, (const bf16_t*)b, (bf16_t*)y, (long long)R, N, K, act);
+        EGOMI_LAUNCH((linear_smallk_kernel<float, bf16_t>), g, bl, 0, s, (const float*)x, (const bf16_t*)w, (const bf16_t*)b, (bf16_t*)y, (long long)R, N, K, act);
     else if (x_dtype == EGOMI_BF16 && dtype == EGOMI_BF16)
-        hipLaunchKernelGGL((linear_smallk_kernel<bf16_t, bf16_t>), g, bl, 0, s, (const bf16_t*)x, (const bf16_t*)w, (const bf16_t*)b, (bf16_t*)y, (long long)R, N, K, act);
+        EGOMI_LAUNCH((linear_smallk_kernel<bf16_t, bf16_t>), g, bl, 0, s, (const bf16_t*)x, (const bf16_t*)w, (const bf16_t*)b, (bf16_t*)y, (long long)R, N, K, act);
     else return EGOMI_E_BADARG;
     return egomi_launch_status();
 }

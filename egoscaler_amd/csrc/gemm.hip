@@ -188,10 +188,10 @@ static int launch_generic(const egomi_gemm_desc* d, hipStream_t s) {
     dim3 grid((d->N + GT_BN - 1) / GT_BN, (d->M + GT_BM - 1) / GT_BM, d->batch > 0 ? d->batch : 1);
     dim3 block(GT_THREADS);
     const bool TA = d->a_layout == 1, TB = d->b_layout == 1;
-    if (!TA && !TB) hipLaunchKernelGGL((gemm_generic_kernel<T, TC, false, false>), grid, block, 0, s, g, aa, ba);
-    else if (!TA && TB) hipLaunchKernelGGL((gemm_generic_kernel<T, TC, false, true>), grid, block, 0, s, g, aa, ba);
-    else if (TA && !TB) hipLaunchKernelGGL((gemm_generic_kernel<T, TC, true, false>), grid, block, 0, s, g, aa, ba);
-    else hipLaunchKernelGGL((gemm_generic_kernel<T, TC, true, true>), grid, block, 0, s, g, aa, ba);
+    if (!TA && !TB) EGOMI_LAUNCH((gemm_generic_kernel<T, TC, false, false>), grid, block, 0, s, g, aa, ba);
+    else if (!TA && TB) EGOMI_LAUNCH((gemm_generic_kernel<T, TC, false, true>), grid, block, 0, s, g, aa, ba);
+    else if (TA && !TB) EGOMI_LAUNCH((gemm_generic_kernel<T, TC, true, false>), grid, block, 0, s, g, aa, ba);
+    else EGOMI_LAUNCH((gemm_generic_kernel<T, TC, true, true>), grid, block, 0, s, g, aa, ba);
     return egomi_launch_status();
 }
 

@@ -220,10 +220,10 @@ extern "C" int egomi_unproject_gather(const uint8_t* rgb, const float* depth, co
     int32_t* cnt = (int32_t*)((char*)workspace + mask_bytes);
     hipStream_t s = (hipStream_t)stream;
     dim3 grid(p.nchunks, B);
-    hipLaunchKernelGGL(unp_mask_kernel, grid, dim3(UNP_THREADS), 0, s, p, mask, cnt);
-    hipLaunchKernelGGL(unp_scan_kernel, dim3(B), dim3(1024), 0, s, cnt, p.nchunks, n_out, out_count);
+    EGOMI_LAUNCH(unp_mask_kernel, grid, dim3(UNP_THREADS), 0, s, p, mask, cnt);
+    EGOMI_LAUNCH(unp_scan_kernel, dim3(B), dim3(1024), 0, s, cnt, p.nchunks, n_out, out_count);
     const long long cap = n_out > 0 ? n_out : L;
-    hipLaunchKernelGGL(unp_write_kernel, grid, dim3(UNP_THREADS), 0, s, p, mask, cnt, out_count, n_out, cap, out_points, out_colors);
+    EGOMI_LAUNCH(unp_write_kernel, grid, dim3(UNP_THREADS), 0, s, p, mask, cnt, out_count, n_out, cap, out_points, out_colors);
     return egomi_launch_status();
 }
 
@@ -279,7 +279,7 @@ __global__ __launch_bounds__(1024) void pc_norm_kernel(const double* points, con
 extern "C" int egomi_pc_norm(const double* points, const float* colors, float* out, int B, int N, egomi_stream_t stream) {
     if (!points || !colors || !out) return EGOMI_E_BADARG;
     if (B <= 0 || N <= 0) return EGOMI_E_SHAPE;
-    hipLaunchKernelGGL(pc_norm_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, points, colors, out, N);
+    EGOMI_LAUNCH(pc_norm_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, points, colors, out, N);
     return egomi_launch_status();
 }
 
@@ -372,7 +372,7 @@ extern "C" int egomi_fps(const float* pts, int B, int N, int C, const int32_t* s
 #define FPS_LAUNCH(P)                                                                                       \
     do {                                                                                                    \
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fps_kernel<P>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL(fps_kernel<P>, dim3(B), dim3(FPS_THREADS), lds, s, pts, N, C, start, G, out_idx, out_center); \
+        EGOMI_LAUNCH(fps_kernel<P>, dim3(B), dim3(FPS_THREADS), lds, s, pts, N, C, start, G, out_idx, out_center); \
     } while (0)
     if (ppt <= 1) FPS_LAUNCH(1);
     else if (ppt <= 2) FPS_LAUNCH(2);
@@ -466,9 +466,9 @@ extern "C" int egomi_knn_group(const float* pts, const float* center, int B, int
     const int blocks = (total + KNN_WAVES - 1) / KNN_WAVES;
     hipStream_t s = (hipStream_t)stream;
     if (out_dtype == EGOMI_F32)
-        hipLaunchKernelGGL(knn_group_kernel<float>, dim3(blocks), dim3(KNN_WAVES * 64), 0, s, pts, center, N, C, G, K, total, out_idx, (float*)out_nb);
+        EGOMI_LAUNCH(knn_group_kernel<float>, dim3(blocks), dim3(KNN_WAVES * 64), 0, s, pts, center, N, C, G, K, total, out_idx, (float*)out_nb);
     else if (out_dtype == EGOMI_BF16)
-        hipLaunchKernelGGL(knn_group_kernel<bf16_t>, dim3(blocks), dim3(KNN_WAVES * 64), 0, s, pts, center, N, C, G, K, total, out_idx, (bf16_t*)out_nb);
+        EGOMI_LAUNCH(knn_group_kernel<bf16_t>, dim3(blocks), dim3(KNN_WAVES * 64), 0, s, pts, center, N, C, G, K, total, out_idx, (bf16_t*)out_nb);
     else
         return EGOMI_E_BADARG;
     return egomi_launch_status();

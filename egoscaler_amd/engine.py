@@ -50,6 +50,11 @@ class Engine:
         self.main_grad: Dict[str, torch.Tensor] = {}     # fp32 gradient buffers of trainable tensors
         self.trainable: Dict[str, bool] = {}
         self.ctx = None
+        self.grad_sync = None          # optional dp.GradSync: notified when a gradient buffer is final
+
+    def _notify(self, name):
+        if self.grad_sync is not None and name in self.trainable and name in self.main_grad:
+            self.grad_sync.ready(name, self.main_grad[name])
 
     # ------------------------------------------------------------------------------------ setup
     def prepare(self):
@@ -343,6 +348,7 @@ class Engine:
         tr = self.trainable
         dw = self.grad_buffer("model.norm.weight") if "model.norm.weight" in tr else None
         dx = ops.rmsnorm_bwd(d_hn, ctx["x_last"], w["model.norm.weight"], ctx["rstd_f"], dw=dw, out=ws.get("dx_a", (M, d), T))
+        self._notify("model.norm.weight")
         for l in reversed(range(L)):
             p = f"model.layers.{l}."
             lc = ctx["layers"][l]
@@ -374,6 +380,9 @@ class Engine:
             n1 = p + "input_layernorm.weight"
             dx = ops.rmsnorm_bwd(d_h, lc["x_in"], w[n1], lc["rstd1"], dx_add=d_mid,
                                  dw=self.grad_buffer(n1) if n1 in tr else None, out=ws.get("dx_a", (M, d), T))
+            if self.grad_sync is not None:
+                for nm in self.layer_param_names(l):
+                    self._notify(nm)
         # ---- embedding + splice + projector (pointllm.py:107,126-129,155)
         Pn = pb.point_token_len
         V = lm.vocab_size
@@ -393,11 +402,22 @@ class Engine:
                 if j > 0:
                     g_in = ops.mm(g, w[Wn], out=ws.get(f"d_pp_act{j}", (B * Pn, w[Wn].shape[1]), T), b_layout=1)
                     g = ops.gelu_bwd(g_in, acts[2 * j - 1], out=ws.get(f"d_pp_pre{j}", g_in.shape, T))
+        if self.grad_sync is not None:
+            self._notify(emb_name)
+            for j in range(len(pb.projection_hidden_dim) + 1):
+                self._notify(f"model.point_proj.{2 * j}.weight")
+                self._notify(f"model.point_proj.{2 * j}.bias")
         self.ctx = None
+
+    def layer_param_names(self, l):
+        p = f"model.layers.{l}."
+        return [p + f"self_attn.{n}_proj.weight" for n in "qkvo"] + [p + f"mlp.{n}_proj.weight" for n in ("gate", "up", "down")] + \
+               [p + "input_layernorm.weight", p + "post_attention_layernorm.weight"]
 
     def backward_logits(self, d_logits, hn):
         """lm_head backward: d_hn = d_logits . W ; dW += d_logits^T . hn."""
         W = self.w["lm_head.weight"]
         d_hn = ops.mm(d_logits, W, out=self.ws.get("d_hn", hn.shape, self.dtype), b_layout=1)
         self._wgrad("lm_head.weight", d_logits, hn)
+        self._notify("lm_head.weight")
         return d_hn

@@ -73,9 +73,13 @@ def pc_norm(points, colors):
 def fps(pts, start, num_group):
     pts = _c(pts, torch.float32)
     B, N, C = pts.shape
-    start = _c(torch.as_tensor(start, device=pts.device), torch.int32)
-    if start.numel() != B or int(start.min()) < 0 or int(start.max()) >= N:
-        raise ValueError("fps: start must hold one index in [0,N) per cloud")
+    if torch.is_tensor(start) and start.is_cuda and start.dtype == torch.int32 and start.numel() == B:
+        start = start.contiguous()          # resident start vector: validated by its producer (no host sync here)
+    else:
+        host = torch.as_tensor(start).reshape(-1).to(torch.int64).cpu()
+        if host.numel() != B or int(host.min()) < 0 or int(host.max()) >= N:
+            raise ValueError("fps: start must hold one index in [0,N) per cloud")
+        start = host.to(torch.int32).to(pts.device)
     idx = torch.empty(B, num_group, dtype=torch.int32, device=pts.device)
     cen = torch.empty(B, num_group, 3, dtype=torch.float32, device=pts.device)
     call("egomi_fps", P(pts), c_i(B), c_i(N), c_i(C), P(start), c_i(num_group), P(idx), P(cen), S())
@@ -106,6 +110,25 @@ class GemmDesc(ctypes.Structure):
 ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
 
 
+class GemmProfiler:
+    """HIP-event timing of GEMM launches on the stream they are launched on (bench.py roofline)."""
+
+    def __init__(self, min_flops=1e9):
+        self.min_flops, self.recs, self.enabled = min_flops, [], True
+
+    def summary(self):
+        torch.cuda.synchronize()
+        n, flops, ms = 0, 0.0, 0.0
+        for e0, e1, f in self.recs:
+            n += 1
+            flops += f
+            ms += e0.elapsed_time(e1)
+        return {"launches": n, "flops": flops, "ms": ms}
+
+
+PROFILER = None
+
+
 def gemm_raw(A, B, C, M, N, K, lda, ldb, ldc, a_layout=0, b_layout=0, bias=None, residual=None, ldr=0,
              act=0, alpha=1.0, accumulate=False, batch=1, batch_inner=1, strides=(0, 0, 0, 0, 0, 0), force_generic=False):
     """C = act(alpha*A.B + bias) + residual (+C).  A/B/C are tensors whose data_ptr() is the first
@@ -130,7 +153,16 @@ def gemm_raw(A, B, C, M, N, K, lda, ldb, ldc, a_layout=0, b_layout=0, bias=None,
     for t in (A, B, C):
         if not t.is_cuda:
             raise _lib.EgomiError("gemm needs device tensors")
-    call("egomi_gemm", ctypes.byref(d), S())
+    prof = PROFILER
+    flops = 2.0 * M * N * K * max(1, batch)
+    if prof is not None and prof.enabled and flops >= prof.min_flops:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        call("egomi_gemm", ctypes.byref(d), S())
+        e1.record()
+        prof.recs.append((e0, e1, flops))
+    else:
+        call("egomi_gemm", ctypes.byref(d), S())
     return C
 
 

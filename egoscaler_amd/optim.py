@@ -1,0 +1,49 @@
+"""AdamW over the engine's fp32 main_grad buffers (reference optimizer: train.py:107-117,
+AdamW lr 2e-5 + linear warm-up over 1/5 of the steps; DeepSpeed keeps fp32 master weights for bf16
+params, train.py:97-98 — same here, without ZeRO sharding: 288 GB holds everything replicated)."""
+import torch
+
+from . import ops
+
+
+class EgoAdamW:
+    def __init__(self, model, lr=2e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01):
+        self.model, self.lr, self.betas, self.eps, self.wd = model, lr, betas, eps, weight_decay
+        self.t = 0
+        self.state = {}
+        for n, p in model.named_parameters():
+            if p.requires_grad:
+                master = p.data if p.dtype == torch.float32 else p.data.float()
+                self.state[n] = {"p": p, "master": master, "m": torch.zeros_like(master), "v": torch.zeros_like(master)}
+
+    def step(self, grad_scale=1.0, lr=None):
+        self.t += 1
+        lr = self.lr if lr is None else lr
+        eng = self.model.engine
+        for n, st in self.state.items():
+            g = eng.main_grad.get(n)
+            if g is None:
+                continue
+            p = st["p"]
+            copy = None if p.dtype == torch.float32 else p.data
+            ops.adamw(st["master"], copy, g, st["m"], st["v"], lr, self.betas[0], self.betas[1], self.eps, self.wd, self.t, grad_scale)
+
+    def zero_grad(self):
+        self.model.engine.zero_grad()
+        for st in self.state.values():
+            st["p"].grad = None
+
+    def state_dict(self):
+        return {"t": self.t, "state": {n: {k: st[k] for k in ("master", "m", "v")} for n, st in self.state.items()}}
+
+    def load_state_dict(self, sd):
+        self.t = sd["t"]
+        for n, s in sd["state"].items():
+            for k in ("master", "m", "v"):
+                self.state[n][k].copy_(s[k])
+
+
+def linear_warmup_lr(base_lr, step, total_steps):
+    """train.py:113-117: linear warm-up over the first fifth of the steps, then constant."""
+    warm = max(1, total_steps // 5)
+    return base_lr * min(1.0, (step + 1) / warm)

@@ -38,6 +38,8 @@ typedef void* egomi_stream_t;
 
 int egomi_version(void);
 const char* egomi_strerror(int code);
+/* HIP's message for the most recent failed launch on this thread (diagnostics for EGOMI_E_LAUNCH) */
+const char* egomi_last_launch_error(void);
 
 /* ------------------------------------------------------------------------------------------------
  * A1  RGB-D un-projection + ordered compaction (+ optional strided subsample)
