@@ -1,3 +1,206 @@
-// Tuned bf16 NT GEMM for the LLaMA-sized projections (placeholder: not yet applicable to any shape).
+// Tuned bf16 "NT" GEMM for the LLaMA-sized projections:  C[M,N] = A[M,K] . B[N,K]^T  (+ epilogue)
+//   * both operands K-contiguous (activation x nn.Linear weight; dgrad uses pre-transposed weights,
+//     wgrad uses transposed activations, so every big product of the path has this form)
+//   * 128x128x64 tile, 256 threads (4 waves, 2x2), v_mfma_f32_16x16x32_bf16, fp32 accumulate
+//   * global -> LDS by LDS-DMA (global_load_lds_dwordx4): no staging VGPRs, no ds_write
+//   * LDS image linear [row][64 k] (128-B rows); bank conflicts removed by an XOR swizzle applied to
+//     the per-lane SOURCE address and to the fragment read (chunk ^= (row>>1)&7): the 16 rows of a
+//     fragment land on 16 distinct 16-B slots of the 256-B bank row (cdna_hip_programming.md rule 21)
+//   * operands are fed swapped (weights as the MFMA A operand) so each lane's 4 accumulators are 4
+//     consecutive output columns -> 8-B / 16-B epilogue stores
+//   * rows beyond M / N are clamped on load and masked on store; K % 64 == 0
+//   * XCD-aware block order: the 8 XCDs each walk a contiguous strip of M-tiles, N fastest, so one
+//     XCD's L2 keeps its A rows while the B panels stream (T1)
 #include "common.h"
-int egomi_gemm_fast_try(const egomi_gemm_desc* d, hipStream_t s) { (void)d; (void)s; return 1; }
+
+#define FT_BM 128
+#define FT_BN 128
+#define FT_BK 64
+#define FT_THREADS 256
+
+struct FastArgs {
+    const bf16_t* A; const bf16_t* B; void* C; const bf16_t* bias; const void* residual;
+    int M, N, K;
+    long long lda, ldb, ldc, ldr;
+    float alpha; int accumulate; int act;
+    int tiles_m, tiles_n;
+};
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef __attribute__((address_space(1))) const void gbl_void;
+
+__device__ __forceinline__ void glds16(const bf16_t* g, bf16_t* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((gbl_void*)g, (lds_void*)lds_wave_base, 16, 0, 0);
+}
+
+template <typename TC>
+__global__ __launch_bounds__(FT_THREADS, 3) void gemm_nt_bf16_kernel(FastArgs g) {
+    __shared__ __attribute__((aligned(16))) bf16_t smem[(FT_BM + FT_BN) * FT_BK];     // 32 KB, one array
+    bf16_t* sA = smem;
+    bf16_t* sB = smem + FT_BM * FT_BK;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+
+    // ---- XCD-aware tile order (bijective for any grid size)
+    const int nwg = g.tiles_m * g.tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    // grouped order inside the strip: 8 M-tiles x consecutive N-tiles run together, so the ~64 tiles an
+    // XCD has in flight form a square block that re-uses both A rows and B panels from its L2
+    const int per_group = 8 * g.tiles_n;
+    const int grp = bid / per_group, first_tm = grp * 8;
+    const int gsz = (g.tiles_m - first_tm) < 8 ? (g.tiles_m - first_tm) : 8;
+    const int in_g = bid - grp * per_group;
+    const int tm = first_tm + in_g % gsz, tn = in_g / gsz;
+    const int m0 = tm * FT_BM, n0 = tn * FT_BN;
+
+    // ---- per-lane LDS-DMA source pointers (4 pieces of 8 rows x 128 B per operand per wave)
+    const bf16_t* srcA[4];
+    const bf16_t* srcB[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = (wave * 4 + i) * 8 + (lane >> 3);             // row inside the tile
+        const int chunk = (lane & 7) ^ ((r >> 1) & 7);              // swizzled 16-B chunk of the row
+        int ra = m0 + r; ra = ra < g.M ? ra : g.M - 1;
+        int rb = n0 + r; rb = rb < g.N ? rb : g.N - 1;
+        srcA[i] = g.A + (long long)ra * g.lda + chunk * 8;
+        srcB[i] = g.B + (long long)rb * g.ldb + chunk * 8;
+    }
+
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    f32x4 acc[4][4];                                                // [n-tile j][m-tile i]
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // fragment read offsets (bytes are 2*elements): row (lane&15), chunk (lane>>4) + 4*ks, swizzled
+    int offA[4], offB[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int ra = wm + i * 16 + (lane & 15);
+        const int rb = wn + i * 16 + (lane & 15);
+        offA[i] = ra * FT_BK;
+        offB[i] = rb * FT_BK;
+    }
+    const int sw_a = ((wm + (lane & 15)) >> 1) & 7;                 // (row>>1)&7 is the same for every 16-row tile of the wave
+    const int sw_b = ((wn + (lane & 15)) >> 1) & 7;
+    const int c0 = lane >> 4;
+
+    const int nt = g.K / FT_BK;
+    for (int t = 0; t < nt; ++t) {
+        const int k0 = t * FT_BK;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) glds16(srcA[i] + k0, sA + (wave * 4 + i) * 8 * FT_BK);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) glds16(srcB[i] + k0, sB + (wave * 4 + i) * 8 * FT_BK);
+        __syncthreads();                                            // emits vmcnt(0): the DMA has landed
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 fa[4], fb[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                fa[i] = *reinterpret_cast<const bf16x8*>(sA + offA[i] + (((c0 + 4 * ks) ^ sw_a) << 3));
+                fb[i] = *reinterpret_cast<const bf16x8*>(sB + offB[i] + (((c0 + 4 * ks) ^ sw_b) << 3));
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[j][i], 0, 0, 0);
+        }
+        __syncthreads();                                            // tile consumed before it is overwritten
+    }
+
+    // ---- epilogue.  acc[j][i][r] = C[m][n], n = n0+wn+16j+4*(lane>>4)+r, m = m0+wm+16i+(lane&15)
+    TC* C = reinterpret_cast<TC*>(g.C);
+    const TC* R = reinterpret_cast<const TC*>(g.residual);
+    const bool vec_ok = (g.ldc % 4 == 0) && (!R || g.ldr % 4 == 0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int n = n0 + wn + j * 16 + (lane >> 4) * 4;
+        if (n >= g.N) continue;
+        float bv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (g.bias) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) if (n + r < g.N) bv[r] = bf2f(g.bias[n + r]);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = m0 + wm + i * 16 + (lane & 15);
+            if (m >= g.M) continue;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = act_apply(acc[j][i][r] * g.alpha + bv[r], g.act);
+            TC* cp = C + (long long)m * g.ldc + n;
+            const TC* rp = R ? R + (long long)m * g.ldr + n : nullptr;
+            if (n + 3 < g.N && vec_ok) {
+                if (sizeof(TC) == 2) {
+                    if (rp) {
+                        const u32x2 rr = *reinterpret_cast<const u32x2*>(rp);
+                        v[0] += __uint_as_float(rr[0] << 16); v[1] += __uint_as_float(rr[0] & 0xFFFF0000u);
+                        v[2] += __uint_as_float(rr[1] << 16); v[3] += __uint_as_float(rr[1] & 0xFFFF0000u);
+                    }
+                    if (g.accumulate) {
+                        const u32x2 cc = *reinterpret_cast<const u32x2*>(cp);
+                        v[0] += __uint_as_float(cc[0] << 16); v[1] += __uint_as_float(cc[0] & 0xFFFF0000u);
+                        v[2] += __uint_as_float(cc[1] << 16); v[3] += __uint_as_float(cc[1] & 0xFFFF0000u);
+                    }
+                    u32x2 o;
+                    o[0] = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+                    o[1] = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+                    *reinterpret_cast<u32x2*>(cp) = o;
+                } else {
+                    f32x4 o = {v[0], v[1], v[2], v[3]};
+                    if (rp) o += *reinterpret_cast<const f32x4*>(rp);
+                    if (g.accumulate) o += *reinterpret_cast<const f32x4*>(cp);
+                    *reinterpret_cast<f32x4*>(cp) = o;
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (n + r >= g.N) continue;
+                    float x = v[r];
+                    if (rp) x += Cvt<TC>::ld(rp + r);
+                    if (g.accumulate) x += Cvt<TC>::ld(cp + r);
+                    Cvt<TC>::st(cp + r, x);
+                }
+            }
+        }
+    }
+}
+
+static bool fast_applicable(const egomi_gemm_desc* d) {
+    if (d->ab_dtype != EGOMI_BF16 || d->a_layout != 0 || d->b_layout != 0) return false;
+    if (d->batch > 1) return false;
+    if (d->K % FT_BK || d->K < FT_BK) return false;
+    if (d->lda % 8 || d->ldb % 8) return false;
+    if (((uintptr_t)d->A | (uintptr_t)d->B) & 15) return false;
+    const int esz = d->c_dtype == EGOMI_BF16 ? 2 : 4;
+    if (((uintptr_t)d->C % (4 * esz)) || (d->residual && ((uintptr_t)d->residual % (4 * esz)))) return false;
+    if ((long long)d->M * d->N < 128 * 128) return false;          // tiny products: the generic kernel is fine
+    return true;
+}
+
+extern "C" int egomi_gemm_kernel_id(const egomi_gemm_desc* d) {
+    if (!d) return EGOMI_E_BADARG;
+    return (!d->force_generic && fast_applicable(d)) ? 1 : 0;
+}
+
+// returns 0 on success, <0 on error, 1 when the tuned kernel does not apply
+int egomi_gemm_fast_try(const egomi_gemm_desc* d, hipStream_t s) {
+    if (!fast_applicable(d)) return 1;
+    FastArgs g;
+    g.A = (const bf16_t*)d->A; g.B = (const bf16_t*)d->B; g.C = d->C; g.bias = (const bf16_t*)d->bias; g.residual = d->residual;
+    g.M = d->M; g.N = d->N; g.K = d->K; g.lda = d->lda; g.ldb = d->ldb; g.ldc = d->ldc; g.ldr = d->ldr;
+    g.alpha = d->alpha; g.accumulate = d->accumulate; g.act = d->act;
+    g.tiles_m = (d->M + FT_BM - 1) / FT_BM; g.tiles_n = (d->N + FT_BN - 1) / FT_BN;
+    const int nwg = g.tiles_m * g.tiles_n;
+    if (d->c_dtype == EGOMI_BF16) EGOMI_LAUNCH(gemm_nt_bf16_kernel<bf16_t>, dim3(nwg), dim3(FT_THREADS), 0, s, g);
+    else if (d->c_dtype == EGOMI_F32) EGOMI_LAUNCH(gemm_nt_bf16_kernel<float>, dim3(nwg), dim3(FT_THREADS), 0, s, g);
+    else return EGOMI_E_UNSUPPORTED;
+    return egomi_launch_status();
+}

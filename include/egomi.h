@@ -113,6 +113,8 @@ typedef struct egomi_gemm_desc {
     int force_generic;   /* 1: never take the tuned kernel (used by tests to cross-check it) */
 } egomi_gemm_desc;
 int egomi_gemm(const egomi_gemm_desc* desc, egomi_stream_t stream);
+/* which kernel egomi_gemm would run for this descriptor: 1 = tuned bf16 NT kernel, 0 = generic */
+int egomi_gemm_kernel_id(const egomi_gemm_desc* desc);
 
 /* ------------------------------------------------------------------------------------------------
  * Row / elementwise kernels (HBM-bound).  `dtype` is the activation/parameter dtype T.

@@ -267,3 +267,32 @@ def test_transpose_cast_add_groupmax_smallk(ops, dtype):
     x6 = rnd(64, 6, dtype=dtype, seed=5)
     w6 = rnd(128, 6, dtype=dtype, seed=6)
     close(ops.linear_smallk(x6.cuda(), w6.cuda(), b.cuda(), act=ops.ACT_RELU), F.relu(x6.float() @ w6.float().t() + b.float()), TOL[dtype])
+
+
+@pytest.mark.parametrize("M,N,K", [(700, 4096, 4096), (128, 128, 64), (1280, 1024, 11008), (300, 2018, 384), (5536, 256, 512)])
+def test_gemm_tuned_nt_kernel(ops, M, N, K):
+    """The tuned bf16 NT kernel (LDS-DMA staging, swizzled LDS, clamped edge rows) against fp32 CPU
+    matmul and against the generic kernel on the same inputs."""
+    a, w = rnd(M, K, dtype=torch.bfloat16, seed=11), rnd(N, K, dtype=torch.bfloat16, seed=12, scale=0.05)
+    bias, res = rnd(N, dtype=torch.bfloat16, seed=13), rnd(M, N, dtype=torch.bfloat16, seed=14)
+    A, W, Bi, R = a.cuda(), w.cuda(), bias.cuda(), res.cuda()
+    ref = a.float() @ w.float().t()
+    fast = ops.mm(A, W)
+    gen = ops.mm(A, W, force_generic=True)
+    close(fast, ref, 2e-2)
+    assert float((fast.float() - gen.float()).abs().max()) <= 2e-2 * float(ref.abs().max())
+    close(ops.mm(A, W, bias=Bi, act=ops.ACT_GELU, residual=R, alpha=0.5), torch.nn.functional.gelu(0.5 * ref + bias.float()) + res.float(), 2e-2)
+    acc = torch.full((M, N), 2.0, dtype=torch.float32, device="cuda")
+    ops.mm(A, W, out=acc, accumulate=True)
+    close(acc, ref + 2.0, 2e-2)
+    big = torch.zeros(M, N + 64, dtype=torch.bfloat16, device="cuda")
+    ops.mm(A, W, out=big[:, 32:32 + N] if N % 4 == 0 else big[:, :N])
+    close(big[:, 32:32 + N] if N % 4 == 0 else big[:, :N], ref, 2e-2)
+    # kernel selection is what the test thinks it is
+    d = ops.GemmDesc()
+    d.A, d.B, d.C = A.data_ptr(), W.data_ptr(), fast.data_ptr()
+    d.M, d.N, d.K, d.lda, d.ldb, d.ldc = M, N, K, K, K, N
+    d.ab_dtype, d.c_dtype, d.batch = 1, 1, 1
+    import ctypes
+    from egoscaler_amd import _lib
+    assert _lib.lib().egomi_gemm_kernel_id(ctypes.byref(d)) == 1
