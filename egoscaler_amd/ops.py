@@ -113,8 +113,8 @@ ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
 class GemmProfiler:
     """HIP-event timing of GEMM launches on the stream they are launched on (bench.py roofline)."""
 
-    def __init__(self, min_flops=1e9):
-        self.min_flops, self.recs, self.enabled = min_flops, [], True
+    def __init__(self, min_flops=1e9, tuned_only=True):
+        self.min_flops, self.recs, self.enabled, self.tuned_only = min_flops, [], True, tuned_only
 
     def summary(self):
         torch.cuda.synchronize()
@@ -155,7 +155,8 @@ def gemm_raw(A, B, C, M, N, K, lda, ldb, ldc, a_layout=0, b_layout=0, bias=None,
             raise _lib.EgomiError("gemm needs device tensors")
     prof = PROFILER
     flops = 2.0 * M * N * K * max(1, batch)
-    if prof is not None and prof.enabled and flops >= prof.min_flops:
+    if prof is not None and prof.enabled and flops >= prof.min_flops and \
+            (not prof.tuned_only or _lib.lib().egomi_gemm_kernel_id(ctypes.byref(d)) == 1):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         call("egomi_gemm", ctypes.byref(d), S())
