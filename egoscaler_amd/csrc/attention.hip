@@ -1,0 +1,507 @@
+// Fused attention for the LLaMA layers (head_dim 128, bf16, causal + key-padding mask):
+// forward with online softmax, and a deterministic two-kernel backward (dK/dV kernel, dQ kernel).
+// Replaces HF eager_attention_forward (modeling_llama.py:191-214: scores + mask, fp32 softmax,
+// P.V) and its autograd backward; the [S,S] score matrix never touches HBM.
+//
+// Orientation (cdna_hip_programming.md §3 "An accumulator tile as the next MFMA's operand"):
+//   forward / dQ kernel:  X = K.Q^T  (32 keys x 32 queries, v_mfma_f32_32x32x16_bf16)  -> the QUERY
+//     sits on the lane, so running max / sum / LSE / delta are lane-local; P (bf16) is then fed
+//     back as the B operand of  O^T += V^T.P^T  (resp. dQ^T += K^T.dS^T) with no lane movement,
+//     V^T / K^T fragments coming from ds_read_b64_tr_b16 on row-major LDS tiles.
+//   dK/dV kernel:  X = Q.K^T (32 queries x 32 keys) -> the KEY sits on the lane; -LSE/scale and
+//     -delta enter as initial accumulators; dV^T += dO^T.P, dK^T += Q^T.dS.
+// LDS tiles are [rows][128] bf16 (256-B rows) with the dual-use swizzle
+//   off(row, ch) = 256*row + 16*(ch ^ (((row&3)<<2) | ((row>>2)&3)))
+// which is conflict-free for both the b128 row reads and the transposed reads (T10 image (b)).
+#include "common.h"
+#include <math.h>
+
+#define AT_HD 128
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
+typedef __attribute__((address_space(3))) bf16x4_t lds_bf16x4;
+
+struct AttnArgs {
+    const bf16_t* q; const bf16_t* k; const bf16_t* v; bf16_t* o; float* lse;
+    const bf16_t* dout; const float* delta; bf16_t* dq; bf16_t* dk; bf16_t* dv;
+    const uint8_t* key_mask;
+    int B, H, S;
+    long long ld_qkv, ld_o, ld_dqkv;
+    float scale;
+    int causal;
+};
+
+__device__ __forceinline__ int sw_off(int row, int ch) {            // byte offset inside a [rows][256 B] tile
+    return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3)));
+}
+__device__ __forceinline__ int rowmap(int reg, int half) {          // C/D row of a 32x32 accumulator register
+    return (reg & 3) + 8 * (reg >> 2) + 4 * half;
+}
+__device__ __forceinline__ bf16x8 lds_row8(const char* tile, int row, int ch) {
+    return *reinterpret_cast<const bf16x8*>(tile + sw_off(row, ch));
+}
+// transposed fragment: 8 bf16 = column (col0 + lane&31) of rows {r0 + 4*half + 0..3, r0 + 8 + 4*half + 0..3}
+__device__ __forceinline__ bf16x8 lds_tr8(const char* tile, int r0, int col0, int lane) {
+    const int half = lane >> 5, q = (lane >> 2) & 3, p = lane & 3;
+    const int col = col0 + 16 * ((lane >> 4) & 1) + 4 * p;            // element column this lane points at
+    const int ch = col >> 3, within = (col & 7) * 2;
+    const int ra = r0 + 4 * half + q;
+    const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(tile + sw_off(ra, ch) + within));
+    const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(tile + sw_off(ra + 8, ch) + within));
+    bf16x8 r;
+    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+    r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+    return r;
+}
+__device__ __forceinline__ bf16x8 pack8(const float* v) {
+    bf16x8 r;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = (__bf16)v[j];
+    return r;
+}
+
+// stage ROWS x 128 bf16 rows (row stride ld, rows clamped to [0, row_max]) into a swizzled tile
+template <int ROWS>
+__device__ __forceinline__ void stage_load(u32x4 (&regs)[ROWS * 16 / 256], const bf16_t* base, long long ld, int row0, int row_max) {
+#pragma unroll
+    for (int i = 0; i < ROWS * 16 / 256; ++i) {
+        const int idx = threadIdx.x + 256 * i;
+        int r = row0 + (idx >> 4);
+        r = r < row_max ? r : row_max;
+        regs[i] = *reinterpret_cast<const u32x4*>(base + (long long)r * ld + (idx & 15) * 8);
+    }
+}
+template <int ROWS>
+__device__ __forceinline__ void stage_store(const u32x4 (&regs)[ROWS * 16 / 256], char* tile) {
+#pragma unroll
+    for (int i = 0; i < ROWS * 16 / 256; ++i) {
+        const int idx = threadIdx.x + 256 * i;
+        *reinterpret_cast<u32x4*>(tile + sw_off(idx >> 4, idx & 15)) = regs[i];
+    }
+}
+
+// LDS-DMA one ROWS x 128 bf16 tile (rows clamped to row_max) into a swizzled LDS image: the LDS
+// destination of a wave instruction is linear (4 rows x 16 chunks), so the swizzle goes on the SOURCE.
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void gbl_void_t;
+template <int ROWS>
+__device__ __forceinline__ void tile_dma(const bf16_t* base, long long ld, int row0, int row_max, char* tile, int wave, int lane) {
+#pragma unroll
+    for (int j = 0; j < ROWS / 16; ++j) {
+        const int rl = (wave * (ROWS / 16) + j) * 4 + (lane >> 4);
+        const int ch = (lane & 15) ^ (((rl & 3) << 2) | ((rl >> 2) & 3));
+        int r = row0 + rl;
+        r = r < row_max ? r : row_max;
+        __builtin_amdgcn_global_load_lds((gbl_void_t*)(base + (long long)r * ld + ch * 8),
+                                         (lds_void_t*)(tile + (wave * (ROWS / 16) + j) * 4 * 256), 16, 0, 0);
+    }
+}
+
+// =================================================================================================
+// forward: grid (ceil(S/128), H, B), 4 waves x 32 queries, KV tiles of 64 keys, K/V double-buffered
+// in LDS by LDS-DMA (one tile in flight across the barrier: counted vmcnt + raw s_barrier)
+// =================================================================================================
+#define AT_MAXS 4096
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];       // [2][K 16K | V 16K] + key mask bytes
+    char* sMask = smem + 2 * 2 * 64 * 256;
+    const int lane = threadIdx.x & 63, half = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 128;
+    const long long row_base = (long long)b * a.S;
+    const bf16_t* Q = a.q + row_base * a.ld_qkv + h * AT_HD;
+    const bf16_t* K = a.k + row_base * a.ld_qkv + h * AT_HD;
+    const bf16_t* V = a.v + row_base * a.ld_qkv + h * AT_HD;
+    const int qi = q0 + wave * 32 + (lane & 31);                      // this lane's query
+    const int qr = qi < a.S ? qi : a.S - 1;
+
+    int last = q0 + 127 < a.S - 1 ? q0 + 127 : a.S - 1;
+    const int ntiles = a.causal ? (last / 64 + 1) : ((a.S + 63) / 64);
+    // key-padding mask -> LDS bytes (1 = visible), once
+    for (int j = threadIdx.x; j < ntiles * 64; j += 256) {
+        uint8_t ok = j < a.S;
+        if (ok && a.key_mask) ok = a.key_mask[row_base + j] != 0;
+        sMask[j] = ok;
+    }
+    bf16x8 qf[8];
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(Q + (long long)qr * a.ld_qkv + 16 * ks + 8 * half);
+
+    f32x16 o[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+    const float sc2 = a.scale * 1.4426950408889634f;
+
+    tile_dma<64>(K, a.ld_qkv, 0, a.S - 1, smem, wave, lane);
+    tile_dma<64>(V, a.ld_qkv, 0, a.S - 1, smem + 64 * 256, wave, lane);
+    for (int t = 0; t < ntiles; ++t) {
+        const int kv0 = t * 64;
+        char* sK = smem + (t & 1) * (2 * 64 * 256);
+        char* sV = sK + 64 * 256;
+        if (t + 1 < ntiles) {
+            char* nK = smem + ((t + 1) & 1) * (2 * 64 * 256);
+            tile_dma<64>(K, a.ld_qkv, kv0 + 64, a.S - 1, nK, wave, lane);
+            tile_dma<64>(V, a.ld_qkv, kv0 + 64, a.S - 1, nK + 64 * 256, wave, lane);
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");           // tile t landed; tile t+1 (8 DMAs) stays in flight
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const unsigned long long kmask = __ballot(sMask[kv0 + lane] != 0);
+
+        float s[2][16];
+        float mloc = -INFINITY;
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            f32x16 x;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) x[r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks)
+                x = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_row8(sK, 32 * sub + (lane & 31), 2 * ks + half), qf[ks], x, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int kk = 32 * sub + rowmap(r, half);
+                bool ok = (kmask >> kk) & 1ull;
+                if (a.causal) ok = ok && (kv0 + kk <= qi);
+                const float v = ok ? x[r] * sc2 : -INFINITY;
+                s[sub][r] = v;
+                mloc = fmaxf(mloc, v);
+            }
+        }
+        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+        const float m_new = fmaxf(m_run, mloc);
+        const float m_safe = m_new == -INFINITY ? 0.f : m_new;
+        const float alpha = m_run == -INFINITY ? 0.f : exp2f(m_run - m_safe);
+        float lsum = 0.f;
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float p = exp2f(s[sub][r] - m_safe);            // exp2(-inf) = 0 for masked keys
+                s[sub][r] = p;
+                lsum += p;
+            }
+        lsum += __shfl_xor(lsum, 32, 64);
+        l_run = l_run * alpha + lsum;
+        m_run = m_new;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                const bf16x8 pb = pack8(&s[sub][8 * st]);
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt)
+                    o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_tr8(sV, 32 * sub + 16 * st, 32 * dt, lane), pb, o[dt], 0, 0, 0);
+            }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                                  // buffer (t&1) is free for the DMA of tile t+2
+    }
+    if (qi < a.S) {
+        const float inv = l_run > 0.f ? 1.0f / l_run : 0.f;
+        bf16_t* orow = a.o + (row_base + qi) * a.ld_o + h * AT_HD;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                u32x2 w;
+                w[0] = (uint32_t)f2bf(o[dt][4 * g] * inv) | ((uint32_t)f2bf(o[dt][4 * g + 1] * inv) << 16);
+                w[1] = (uint32_t)f2bf(o[dt][4 * g + 2] * inv) | ((uint32_t)f2bf(o[dt][4 * g + 3] * inv) << 16);
+                *reinterpret_cast<u32x2*>(orow + 32 * dt + 8 * g + 4 * half) = w;
+            }
+        if (half == 0 && a.lse)                                            // natural-log LSE of the SCALED scores
+            a.lse[((long long)b * a.H + h) * a.S + qi] = (m_run == -INFINITY) ? INFINITY : m_run * 0.6931471805599453f + logf(l_run);
+    }
+}
+
+
+// =================================================================================================
+// backward 1/3: delta[b,h,q] = sum_d dO[q,d] * O[q,d]   (one wave per (row, head))
+// =================================================================================================
+__global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* dout, const bf16_t* o, float* delta, int B, int H, int S, long long ld_o) {
+    const long long item = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (item >= (long long)B * S * H) return;
+    const int h = (int)(item % H);
+    const long long row = item / H;
+    const long long off = row * ld_o + h * AT_HD + lane * 2;
+    const uint32_t a = *reinterpret_cast<const uint32_t*>(dout + off), c = *reinterpret_cast<const uint32_t*>(o + off);
+    float v = __uint_as_float(a << 16) * __uint_as_float(c << 16) + __uint_as_float(a & 0xFFFF0000u) * __uint_as_float(c & 0xFFFF0000u);
+    v = wave_sum(v);
+    if (lane == 0) delta[((row / S) * H + h) * S + (row % S)] = v;
+}
+
+// =================================================================================================
+// backward 2/3: dQ.  Same structure as the forward (query on the lane): per 32-key sub-tile
+//   X = K.Q^T, dP^T = V.dO^T, dS^T = P^T*(dP^T - delta), dQ^T += K^T.dS^T
+// =================================================================================================
+__global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* sMask = smem + 2 * 2 * 64 * 256;
+    const int lane = threadIdx.x & 63, half = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 128;
+    const long long row_base = (long long)b * a.S;
+    const bf16_t* Q = a.q + row_base * a.ld_qkv + h * AT_HD;
+    const bf16_t* K = a.k + row_base * a.ld_qkv + h * AT_HD;
+    const bf16_t* V = a.v + row_base * a.ld_qkv + h * AT_HD;
+    const bf16_t* DO = a.dout + row_base * a.ld_o + h * AT_HD;
+    const int qi = q0 + wave * 32 + (lane & 31);
+    const int qr = qi < a.S ? qi : a.S - 1;
+    int last = q0 + 127 < a.S - 1 ? q0 + 127 : a.S - 1;
+    const int ntiles = a.causal ? (last / 64 + 1) : ((a.S + 63) / 64);
+    for (int j = threadIdx.x; j < ntiles * 64; j += 256) {
+        uint8_t ok = j < a.S;
+        if (ok && a.key_mask) ok = a.key_mask[row_base + j] != 0;
+        sMask[j] = ok;
+    }
+    bf16x8 qf[8], dof[8];
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+        qf[ks] = *reinterpret_cast<const bf16x8*>(Q + (long long)qr * a.ld_qkv + 16 * ks + 8 * half);
+        dof[ks] = *reinterpret_cast<const bf16x8*>(DO + (long long)qr * a.ld_o + 16 * ks + 8 * half);
+    }
+    const long long st = ((long long)b * a.H + h) * a.S + qr;
+    const float lse2 = a.lse[st] * 1.4426950408889634f;
+    const float dlt = a.delta[st];
+    const float sc2 = a.scale * 1.4426950408889634f;
+    f32x16 dq[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dq[dt][r] = 0.f;
+
+    tile_dma<64>(K, a.ld_qkv, 0, a.S - 1, smem, wave, lane);
+    tile_dma<64>(V, a.ld_qkv, 0, a.S - 1, smem + 64 * 256, wave, lane);
+    for (int t = 0; t < ntiles; ++t) {
+        const int kv0 = t * 64;
+        char* sK = smem + (t & 1) * (2 * 64 * 256);
+        char* sV = sK + 64 * 256;
+        if (t + 1 < ntiles) {
+            char* nK = smem + ((t + 1) & 1) * (2 * 64 * 256);
+            tile_dma<64>(K, a.ld_qkv, kv0 + 64, a.S - 1, nK, wave, lane);
+            tile_dma<64>(V, a.ld_qkv, kv0 + 64, a.S - 1, nK + 64 * 256, wave, lane);
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const unsigned long long kmask = __ballot(sMask[kv0 + lane] != 0);
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            f32x16 x, dp;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { x[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                x = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_row8(sK, 32 * sub + (lane & 31), 2 * ks + half), qf[ks], x, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_row8(sV, 32 * sub + (lane & 31), 2 * ks + half), dof[ks], dp, 0, 0, 0);
+            }
+            float ds[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int kk = 32 * sub + rowmap(r, half);
+                bool ok = (kmask >> kk) & 1ull;
+                if (a.causal) ok = ok && (kv0 + kk <= qi);
+                const float p = ok ? exp2f(x[r] * sc2 - lse2) : 0.f;
+                ds[r] = p * (dp[r] - dlt);
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const bf16x8 db = pack8(&ds[8 * s2]);
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt)
+                    dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_tr8(sK, 32 * sub + 16 * s2, 32 * dt, lane), db, dq[dt], 0, 0, 0);
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+    if (qi < a.S) {
+        bf16_t* orow = a.dq + (row_base + qi) * a.ld_dqkv + h * AT_HD;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                u32x2 w;
+                w[0] = (uint32_t)f2bf(dq[dt][4 * g] * a.scale) | ((uint32_t)f2bf(dq[dt][4 * g + 1] * a.scale) << 16);
+                w[1] = (uint32_t)f2bf(dq[dt][4 * g + 2] * a.scale) | ((uint32_t)f2bf(dq[dt][4 * g + 3] * a.scale) << 16);
+                *reinterpret_cast<u32x2*>(orow + 32 * dt + 8 * g + 4 * half) = w;
+            }
+    }
+}
+
+// =================================================================================================
+// backward 3/3: dK, dV.  Key on the lane: a workgroup owns 128 keys (4 waves x 32), keeps their K and
+// V fragments and the dK^T / dV^T accumulators in registers (one wave per SIMD, 512-register file) and
+// sweeps the queries in tiles of 32 (Q, dO, LSE, delta tiles double-buffered in LDS by LDS-DMA):
+//   X = Q.K^T, dP = dO.V^T, P = exp2(sc2*X - lse2), dS = P*(dP - delta), dV^T += dO^T.P, dK^T += Q^T.dS
+// =================================================================================================
+#define DKV_STAGE (2 * 32 * 256 + 4 * 256)
+__global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, half = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int b = blockIdx.z, h = blockIdx.y, kb0 = blockIdx.x * 128;
+    const long long row_base = (long long)b * a.S;
+    const bf16_t* Q = a.q + row_base * a.ld_qkv + h * AT_HD;
+    const bf16_t* K = a.k + row_base * a.ld_qkv + h * AT_HD;
+    const bf16_t* V = a.v + row_base * a.ld_qkv + h * AT_HD;
+    const bf16_t* DO = a.dout + row_base * a.ld_o + h * AT_HD;
+    const float* LSE = a.lse + ((long long)b * a.H + h) * a.S;
+    const float* DEL = a.delta + ((long long)b * a.H + h) * a.S;
+    const int kj = kb0 + wave * 32 + (lane & 31);                      // this lane's key
+    const int kr = kj < a.S ? kj : a.S - 1;
+    bool key_ok = kj < a.S;
+    if (key_ok && a.key_mask) key_ok = a.key_mask[row_base + kj] != 0;
+    bf16x8 kf[8], vf[8];
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+        kf[ks] = *reinterpret_cast<const bf16x8*>(K + (long long)kr * a.ld_qkv + 16 * ks + 8 * half);
+        vf[ks] = *reinterpret_cast<const bf16x8*>(V + (long long)kr * a.ld_qkv + 16 * ks + 8 * half);
+    }
+    f32x16 dk[4], dv[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dk[dt][r] = 0.f; dv[dt][r] = 0.f; }
+    const float sc2 = a.scale * 1.4426950408889634f;
+    const int nq = (a.S + 31) / 32;
+    const int qt0 = a.causal ? (kb0 / 32) : 0;
+
+    auto issue = [&](int qt, char* stage) {
+        const int q0 = qt * 32;
+        tile_dma<32>(Q, a.ld_qkv, q0, a.S - 1, stage, wave, lane);
+        tile_dma<32>(DO, a.ld_o, q0, a.S - 1, stage + 32 * 256, wave, lane);
+        int qq = q0 + lane;                                            // 64 floats per DMA; only the first 32 are read
+        qq = qq < a.S ? qq : a.S - 1;
+        const float* src = (wave & 1) ? (DEL + qq) : (LSE + qq);
+        __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(stage + 2 * 32 * 256 + wave * 256), 4, 0, 0);
+    };
+    if (qt0 < nq) issue(qt0, smem);
+    for (int qt = qt0; qt < nq; ++qt) {
+        const int q0 = qt * 32;
+        char* st = smem + ((qt - qt0) & 1) * DKV_STAGE;
+        if (qt + 1 < nq) {
+            issue(qt + 1, smem + ((qt + 1 - qt0) & 1) * DKV_STAGE);
+            asm volatile("s_waitcnt vmcnt(5)" ::: "memory");           // 2 + 2 + 1 DMAs of the next tile stay in flight
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const char* sQ = st;
+        const char* sDO = st + 32 * 256;
+        const float* sL = reinterpret_cast<const float*>(st + 2 * 32 * 256);          // LSE of the 32 queries
+        const float* sD = sL + 64;                                                      // delta (wave 1's piece)
+        f32x16 x, dp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { x[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            x = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_row8(sQ, lane & 31, 2 * ks + half), kf[ks], x, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_row8(sDO, lane & 31, 2 * ks + half), vf[ks], dp, 0, 0, 0);
+        }
+        float pv[16], ds[16];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 l4 = *reinterpret_cast<const f32x4*>(sL + 8 * g + 4 * half);
+            const f32x4 d4 = *reinterpret_cast<const f32x4*>(sD + 8 * g + 4 * half);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int r = 4 * g + e;
+                const int qq = q0 + 8 * g + 4 * half + e;
+                bool ok = key_ok && qq < a.S;
+                if (a.causal) ok = ok && (kj <= qq);
+                const float p = ok ? exp2f(x[r] * sc2 - l4[e] * 1.4426950408889634f) : 0.f;
+                pv[r] = p;
+                ds[r] = p * (dp[r] - d4[e]);
+            }
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const bf16x8 pb = pack8(&pv[8 * s2]);
+            const bf16x8 db = pack8(&ds[8 * s2]);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_tr8(sDO, 16 * s2, 32 * dt, lane), pb, dv[dt], 0, 0, 0);
+                dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_tr8(sQ, 16 * s2, 32 * dt, lane), db, dk[dt], 0, 0, 0);
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+    if (kj < a.S) {
+        bf16_t* krow = a.dk + (row_base + kj) * a.ld_dqkv + h * AT_HD;
+        bf16_t* vrow = a.dv + (row_base + kj) * a.ld_dqkv + h * AT_HD;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                u32x2 w;
+                w[0] = (uint32_t)f2bf(dk[dt][4 * g] * a.scale) | ((uint32_t)f2bf(dk[dt][4 * g + 1] * a.scale) << 16);
+                w[1] = (uint32_t)f2bf(dk[dt][4 * g + 2] * a.scale) | ((uint32_t)f2bf(dk[dt][4 * g + 3] * a.scale) << 16);
+                *reinterpret_cast<u32x2*>(krow + 32 * dt + 8 * g + 4 * half) = w;
+                w[0] = (uint32_t)f2bf(dv[dt][4 * g]) | ((uint32_t)f2bf(dv[dt][4 * g + 1]) << 16);
+                w[1] = (uint32_t)f2bf(dv[dt][4 * g + 2]) | ((uint32_t)f2bf(dv[dt][4 * g + 3]) << 16);
+                *reinterpret_cast<u32x2*>(vrow + 32 * dt + 8 * g + 4 * half) = w;
+            }
+    }
+}
+
+static int attn_check(const egomi_attn_desc* d) {
+    if (!d || !d->q || !d->k || !d->v) return EGOMI_E_BADARG;
+    if (d->B <= 0 || d->H <= 0 || d->S <= 0 || d->head_dim != AT_HD) return d && d->head_dim != AT_HD ? EGOMI_E_UNSUPPORTED : EGOMI_E_SHAPE;
+    if (d->dtype != EGOMI_BF16) return EGOMI_E_UNSUPPORTED;
+    if (d->ld_qkv % 8 || d->ld_qkv < AT_HD * d->H) return EGOMI_E_SHAPE;
+    if (((uintptr_t)d->q | (uintptr_t)d->k | (uintptr_t)d->v) & 15) return EGOMI_E_SHAPE;
+    return EGOMI_OK;
+}
+
+static AttnArgs attn_args(const egomi_attn_desc* d) {
+    AttnArgs a;
+    a.q = (const bf16_t*)d->q; a.k = (const bf16_t*)d->k; a.v = (const bf16_t*)d->v; a.o = (bf16_t*)d->o; a.lse = d->lse;
+    a.dout = (const bf16_t*)d->dout; a.delta = d->delta; a.dq = (bf16_t*)d->dq; a.dk = (bf16_t*)d->dk; a.dv = (bf16_t*)d->dv;
+    a.key_mask = d->key_mask; a.B = d->B; a.H = d->H; a.S = d->S;
+    a.ld_qkv = d->ld_qkv; a.ld_o = d->ld_o; a.ld_dqkv = d->ld_dqkv; a.scale = d->scale; a.causal = d->causal;
+    return a;
+}
+
+extern "C" int egomi_attn_fwd(const egomi_attn_desc* d, egomi_stream_t stream) {
+    const int rc = attn_check(d);
+    if (rc) return rc;
+    if (!d->o || d->ld_o % 4 || d->ld_o < AT_HD * d->H || ((uintptr_t)d->o & 7)) return EGOMI_E_SHAPE;
+    if (d->S > AT_MAXS) return EGOMI_E_UNSUPPORTED;
+    AttnArgs a = attn_args(d);
+    const size_t lds = 2 * 2 * 64 * 256 + (size_t)((d->S + 63) / 64) * 64;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    EGOMI_LAUNCH(attn_fwd_kernel, dim3((d->S + 127) / 128, d->H, d->B), dim3(256), lds, (hipStream_t)stream, a);
+    return egomi_launch_status();
+}
+
+extern "C" int egomi_attn_bwd(const egomi_attn_desc* d, egomi_stream_t stream) {
+    const int rc = attn_check(d);
+    if (rc) return rc;
+    if (!d->o || !d->lse || !d->dout || !d->delta || !d->dq || !d->dk || !d->dv) return EGOMI_E_BADARG;
+    if (d->ld_o % 8 || d->ld_dqkv % 4 || d->ld_o < AT_HD * d->H || d->ld_dqkv < AT_HD * d->H) return EGOMI_E_SHAPE;
+    if (((uintptr_t)d->dout & 15) || (((uintptr_t)d->dq | (uintptr_t)d->dk | (uintptr_t)d->dv) & 7) || ((uintptr_t)d->o & 3)) return EGOMI_E_SHAPE;
+    if (d->S > AT_MAXS) return EGOMI_E_UNSUPPORTED;
+    AttnArgs a = attn_args(d);
+    hipStream_t s = (hipStream_t)stream;
+    const long long items = (long long)d->B * d->S * d->H;
+    EGOMI_LAUNCH(attn_delta_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, s, a.dout, (const bf16_t*)d->o, d->delta, d->B, d->H, d->S, d->ld_o);
+    const size_t lds_q = 2 * 2 * 64 * 256 + (size_t)((d->S + 63) / 64) * 64;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q);
+    EGOMI_LAUNCH(attn_bwd_dq_kernel, dim3((d->S + 127) / 128, d->H, d->B), dim3(256), lds_q, s, a);
+    const size_t lds_k = 2 * DKV_STAGE;
+    EGOMI_LAUNCH(attn_bwd_dkdv_kernel, dim3((d->S + 127) / 128, d->H, d->B), dim3(256), lds_k, s, a);
+    return egomi_launch_status();
+}

@@ -51,6 +51,7 @@ class Engine:
         self.trainable: Dict[str, bool] = {}
         self.ctx = None
         self.grad_sync = None          # optional dp.GradSync: notified when a gradient buffer is final
+        self.use_fused_attention = True
 
     def _notify(self, name):
         if self.grad_sync is not None and name in self.trainable and name in self.main_grad:
@@ -241,6 +242,7 @@ class Engine:
         if attention_mask is not None:
             key_mask = attention_mask.to(device=self.device, dtype=torch.uint8).contiguous()
         scale = hd ** -0.5
+        fused = self.use_fused_attention and T == torch.bfloat16 and hd == 128 and kv_cache is None
         for l in range(L):
             p = f"model.layers.{l}."
             if save:
@@ -250,7 +252,7 @@ class Engine:
                       "gu": torch.empty(M, 2 * Fd, dtype=T, device=self.device)}
                 keep_in = self.any_layer_trainable
                 h = torch.empty(M, d, dtype=T, device=self.device) if keep_in else ws.get("h", (M, d), T)
-                ao = torch.empty(M, d, dtype=T, device=self.device) if keep_in else ws.get("ao", (M, d), T)
+                ao = torch.empty(M, d, dtype=T, device=self.device) if (keep_in or fused) else ws.get("ao", (M, d), T)
                 h2 = torch.empty(M, d, dtype=T, device=self.device) if keep_in else ws.get("h2", (M, d), T)
                 act = torch.empty(M, Fd, dtype=T, device=self.device) if keep_in else ws.get("act", (M, Fd), T)
                 x_mid = torch.empty(M, d, dtype=T, device=self.device)
@@ -267,7 +269,14 @@ class Engine:
             ops.rope_(qkv[:, :d], self.cos, self.sin, M, S, past, H, hd, 3 * d)
             ops.rope_(qkv[:, d:2 * d], self.cos, self.sin, M, S, past, H, hd, 3 * d)
             if kv_cache is None:
-                Pm = self._attention("lm", qkv, B, S, H, hd, ao, True, key_mask, scale, save)
+                lse = None
+                if fused:
+                    # fused flash-style kernel: scores never reach HBM; LSE (and the output) are kept for backward
+                    Pm = None
+                    lse = torch.empty(B, H, S, dtype=torch.float32, device=self.device) if save else ws.get("att_lse", (B, H, S), torch.float32)
+                    ops.attn_fwd(qkv, B, S, H, hd, scale, ao, lse, causal=True, key_mask=key_mask)
+                else:
+                    Pm = self._attention("lm", qkv, B, S, H, hd, ao, True, key_mask, scale, save)
             else:
                 Pm = None
                 self._attention_cached(l, qkv, B, S, H, hd, ao, key_mask, scale, kv_cache)
@@ -278,7 +287,7 @@ class Engine:
             ops.swiglu(gu[:, :Fd], gu[:, Fd:], act)
             ops.mm(act, w[p + "mlp.down_proj.weight"], out=x_out, residual=x_mid)
             if save:
-                lc.update(P=Pm, x_mid=x_mid, h=h, ao=ao, h2=h2, act=act)
+                lc.update(P=Pm, lse=lse, x_mid=x_mid, h=h, ao=ao, h2=h2, act=act)
                 ctx["layers"].append(lc)
             x = x_out
         if kv_cache is not None:
@@ -384,7 +393,11 @@ class Engine:
             d_ao = self._dgrad(d_mid, p + "self_attn.o_proj.weight", ws.get("d_ao", (M, d), T))
             self._wgrad(p + "self_attn.o_proj.weight", d_mid, lc["ao"])
             dqkv = ws.get("dqkv", (M, 3 * d), T)
-            self._attention_bwd(qkv, lc["P"], d_ao, dqkv, B, S, H, hd, scale)
+            if lc["lse"] is not None:
+                ops.attn_bwd(qkv, lc["ao"], lc["lse"], d_ao, dqkv, ws.get("att_delta", (B, H, S), torch.float32), B, S, H, hd, scale,
+                             causal=True, key_mask=ctx["key_mask"])
+            else:
+                self._attention_bwd(qkv, lc["P"], d_ao, dqkv, B, S, H, hd, scale)
             ops.rope_(dqkv[:, :d], self.cos, self.sin, M, S, 0, H, hd, 3 * d, inverse=True)
             ops.rope_(dqkv[:, d:2 * d], self.cos, self.sin, M, S, 0, H, hd, 3 * d, inverse=True)
             d_h = self._dgrad(dqkv[:, :d], p + "self_attn.q_proj.weight", ws.get("d_h", (M, d), T))

@@ -326,3 +326,45 @@ def linear_smallk(x, w, b, act=0, out=None):
     out = torch.empty(R, N, dtype=w.dtype, device=w.device) if out is None else out
     call("egomi_linear_smallk", P(x), c_i(dt(x.dtype)), P(w), P(b), P(out), c_i64(R), c_i(N), c_i(K), c_i(act), c_i(dt(w.dtype)), S())
     return out
+
+
+# ------------------------------------------------------------------------------------------ fused attention
+class AttnDesc(ctypes.Structure):
+    _fields_ = [("q", c_p), ("k", c_p), ("v", c_p), ("o", c_p), ("lse", c_p),
+                ("dout", c_p), ("delta", c_p), ("dq", c_p), ("dk", c_p), ("dv", c_p), ("key_mask", c_p),
+                ("B", c_i), ("H", c_i), ("S", c_i), ("head_dim", c_i),
+                ("ld_qkv", c_i64), ("ld_o", c_i64), ("ld_dqkv", c_i64),
+                ("scale", c_f), ("causal", c_i), ("dtype", c_i)]
+
+
+def _attn_desc(qkv, B, Sq, H, hd, scale, causal, key_mask):
+    d = AttnDesc()
+    dm = H * hd
+    d.q, d.k, d.v = qkv[:, :dm].data_ptr(), qkv[:, dm:2 * dm].data_ptr(), qkv[:, 2 * dm:].data_ptr()
+    d.key_mask = key_mask.data_ptr() if key_mask is not None else None
+    d.B, d.H, d.S, d.head_dim = B, H, Sq, hd
+    d.ld_qkv = qkv.stride(0)
+    d.scale, d.causal, d.dtype = scale, int(causal), dt(qkv.dtype)
+    return d
+
+
+def attn_fwd(qkv, B, Sq, H, hd, scale, out, lse, causal=True, key_mask=None):
+    """qkv [B*S, 3*H*hd] (q|k|v column blocks) -> out [B*S, H*hd], lse fp32 [B,H,S]."""
+    d = _attn_desc(qkv, B, Sq, H, hd, scale, causal, key_mask)
+    d.o, d.lse, d.ld_o = out.data_ptr(), lse.data_ptr() if lse is not None else None, out.stride(0)
+    call("egomi_attn_fwd", ctypes.byref(d), S())
+    return out
+
+
+def attn_bwd(qkv, out, lse, dout, dqkv, delta, B, Sq, H, hd, scale, causal=True, key_mask=None):
+    """dq|dk|dv written into the column blocks of dqkv [B*S, 3*H*hd]; delta fp32 [B,H,S] is scratch."""
+    d = _attn_desc(qkv, B, Sq, H, hd, scale, causal, key_mask)
+    dm = H * hd
+    d.o, d.lse, d.ld_o = out.data_ptr(), lse.data_ptr(), out.stride(0)
+    if dout.stride(0) != out.stride(0):
+        raise ValueError("attn_bwd: dout and out must share their row stride")
+    d.dout, d.delta = dout.data_ptr(), delta.data_ptr()
+    d.dq, d.dk, d.dv = dqkv[:, :dm].data_ptr(), dqkv[:, dm:2 * dm].data_ptr(), dqkv[:, 2 * dm:].data_ptr()
+    d.ld_dqkv = dqkv.stride(0)
+    call("egomi_attn_bwd", ctypes.byref(d), S())
+    return dqkv

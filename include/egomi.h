@@ -117,6 +117,30 @@ int egomi_gemm(const egomi_gemm_desc* desc, egomi_stream_t stream);
 int egomi_gemm_kernel_id(const egomi_gemm_desc* desc);
 
 /* ------------------------------------------------------------------------------------------------
+ * Fused attention (bf16, head_dim 128): softmax(scale * Q.K^T + mask).V without materialising the
+ * [S,S] scores.  replaces HF eager_attention_forward, transformers/models/llama/modeling_llama.py:
+ * 191-214, and its autograd backward (A11).
+ * q/k/v: rows = b*S + s, row stride ld_qkv elements, head h at column h*head_dim (q, k, v may be
+ * three column slices of one [B*S, 3*H*hd] buffer).  o: [B*S, H*hd] row stride ld_o.
+ * mask: key j visible to query i iff (!causal || j <= i) && (key_mask == NULL || key_mask[b*S+j]).
+ * lse [B,H,S] fp32 = log sum exp of the scaled, masked scores (saved for backward).
+ * backward: delta [B,H,S] fp32 = rowsum(dout * o) (egomi_attn_bwd computes it into `delta`), then
+ * dq/dk/dv written with row stride ld_dqkv (deterministic: no atomics).
+ */
+typedef struct egomi_attn_desc {
+    const void* q; const void* k; const void* v; void* o; float* lse;
+    const void* dout; float* delta; void* dq; void* dk; void* dv;
+    const uint8_t* key_mask;
+    int B, H, S, head_dim;
+    int64_t ld_qkv, ld_o, ld_dqkv;
+    float scale;
+    int causal;
+    int dtype;
+} egomi_attn_desc;
+int egomi_attn_fwd(const egomi_attn_desc* desc, egomi_stream_t stream);
+int egomi_attn_bwd(const egomi_attn_desc* desc, egomi_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Row / elementwise kernels (HBM-bound).  `dtype` is the activation/parameter dtype T.
  */
 /* LayerNorm forward with optional fused pre-add: s = x (+ add); y = (s-mean)*rstd*w + b; sum_out = s

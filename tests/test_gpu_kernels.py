@@ -296,3 +296,65 @@ def test_gemm_tuned_nt_kernel(ops, M, N, K):
     import ctypes
     from egoscaler_amd import _lib
     assert _lib.lib().egomi_gemm_kernel_id(ctypes.byref(d)) == 1
+
+
+def _ref_attention(qkv, B, S, H, hd, scale, causal, km):
+    x = qkv.float().view(B, S, 3, H, hd)
+    q, k, v = x[:, :, 0].transpose(1, 2), x[:, :, 1].transpose(1, 2), x[:, :, 2].transpose(1, 2)
+    sc = (q @ k.transpose(-1, -2)) * scale
+    keep = torch.ones(S, S, dtype=torch.bool)
+    if causal:
+        keep = torch.tril(keep)
+    keep = keep[None, None]
+    if km is not None:
+        keep = keep & km.bool()[:, None, None, :]
+    sc = sc.masked_fill(~keep, float("-inf"))
+    lse = torch.logsumexp(sc, -1)
+    return (torch.softmax(sc, -1) @ v).transpose(1, 2).reshape(B * S, H * hd), lse
+
+
+@pytest.mark.parametrize("B,S,H,causal,masked", [(2, 200, 3, True, True), (1, 692, 2, True, False), (2, 64, 1, False, True), (1, 33, 2, True, False), (1, 129, 1, True, True)])
+def test_fused_attention_forward(ops, B, S, H, causal, masked):
+    hd = 128
+    qkv = rnd(B * S, 3 * H * hd, dtype=torch.bfloat16, seed=S)
+    km = None
+    if masked:
+        km = torch.ones(B, S, dtype=torch.uint8)
+        km[-1, S - S // 5:] = 0                       # right padding on the last sample
+    ref, lse_ref = _ref_attention(qkv, B, S, H, hd, hd ** -0.5, causal, km)
+    out = torch.zeros(B * S, H * hd, dtype=torch.bfloat16, device="cuda")
+    lse = torch.zeros(B, H, S, dtype=torch.float32, device="cuda")
+    ops.attn_fwd(qkv.cuda(), B, S, H, hd, hd ** -0.5, out, lse, causal=causal, key_mask=None if km is None else km.cuda())
+    rows = torch.ones(B, S, dtype=torch.bool)
+    if km is not None and not causal:
+        pass
+    close(out, ref, 2e-2)
+    assert float((lse.cpu() - lse_ref).abs().max()) < 2e-2
+
+
+@pytest.mark.parametrize("B,S,H,causal,masked", [(2, 200, 3, True, True), (1, 692, 2, True, False), (2, 64, 1, False, True), (1, 33, 2, True, False), (1, 300, 1, True, True)])
+def test_fused_attention_backward(ops, B, S, H, causal, masked):
+    hd = 128
+    d = H * hd
+    qkv = rnd(B * S, 3 * d, dtype=torch.bfloat16, seed=S + 1)
+    dout = rnd(B * S, d, dtype=torch.bfloat16, seed=S + 2)
+    km = None
+    if masked:
+        km = torch.ones(B, S, dtype=torch.uint8)
+        km[-1, S - S // 5:] = 0
+    x = qkv.float().requires_grad_(True)
+    ref, _ = _ref_attention(x, B, S, H, hd, hd ** -0.5, causal, km)
+    ref.backward(dout.float())
+    out = torch.zeros(B * S, d, dtype=torch.bfloat16, device="cuda")
+    lse = torch.zeros(B, H, S, dtype=torch.float32, device="cuda")
+    Q = qkv.cuda()
+    kmc = None if km is None else km.cuda()
+    ops.attn_fwd(Q, B, S, H, hd, hd ** -0.5, out, lse, causal=causal, key_mask=kmc)
+    dqkv = torch.zeros(B * S, 3 * d, dtype=torch.bfloat16, device="cuda")
+    delta = torch.zeros(B, H, S, dtype=torch.float32, device="cuda")
+    ops.attn_bwd(Q, out, lse, dout.cuda(), dqkv, delta, B, S, H, hd, hd ** -0.5, causal=causal, key_mask=kmc)
+    g = x.grad
+    for i, name in enumerate("qkv"):
+        got, want = dqkv[:, i * d:(i + 1) * d], g[:, i * d:(i + 1) * d]
+        err = (got.float().cpu() - want).abs().max().item()
+        assert err <= 3e-2 * (want.abs().max().item() + 1e-9), (name, err, want.abs().max().item())

@@ -142,3 +142,23 @@ def test_bf16_mode_tracks_fp32(tiny):
     assert abs(float(loss) - float(g["loss"])) < 2e-2 * abs(float(g["loss"]))
     gw = dict(m.named_parameters())["model.point_proj.4.weight"].main_grad
     assert gw.dtype == torch.float32 and rel(gw, g["grad:model.point_proj.4.weight"]) < 0.15
+
+
+def test_fused_attention_path_matches_unfused_path():
+    """bf16, head_dim 128: the flash-style kernels (fwd + two-kernel bwd) against the batched-GEMM +
+    softmax path of the same engine, through the whole model (loss and every trainable gradient)."""
+    dims = dims_tiny()
+    dims.lm.hidden_size, dims.lm.num_attention_heads, dims.lm.intermediate_size = 256, 2, 512
+    toks, masks, Lp = synth.synth_batch(dims, 2, text_len=8, num_steps=4, max_traj_token=40)
+    pts = torch.stack([synth.synth_cloud(dims, i) for i in range(2)])
+    res = {}
+    for fused in (True, False):
+        m = make_model(dims, True, dtype=torch.bfloat16)
+        m.engine.use_fused_attention = fused
+        m.train()
+        loss = m.loss_and_backward(toks.cuda(), masks.cuda(), pts.cuda(), Lp, dims.tok.pad, fps_start=[0, 17])
+        res[fused] = (float(loss), {n: p.main_grad.clone() for n, p in m.named_parameters() if getattr(p, "main_grad", None) is not None})
+    assert abs(res[True][0] - res[False][0]) < 1e-2 * abs(res[False][0])
+    for n, g in res[False][1].items():
+        err = float((res[True][1][n] - g).abs().max())
+        assert err <= 5e-2 * (float(g.abs().max()) + 1e-12), (n, err)
