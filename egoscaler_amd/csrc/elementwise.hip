@@ -194,10 +194,52 @@ __global__ __launch_bounds__(256) void rope_kernel(T* x, const float* cos_tab, c
     }
 }
 
+// 8 rotation pairs per thread: 16-B loads of both halves and 32-B loads of the fp32 tables
+template <typename T>
+__global__ __launch_bounds__(256) void rope_vec8_kernel(T* x, const float* cos_tab, const float* sin_tab, long long rows, int S, int pos_offset,
+                                                        int H, int hd, long long ld, int inverse) {
+    const int half = hd >> 1, cpv = half >> 3;                      // 8-wide chunks per half
+    const long long total = rows * H * cpv;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const int i = (int)(e % cpv) * 8;
+        const int h = (int)((e / cpv) % H);
+        const long long r = e / ((long long)cpv * H);
+        const int pos = pos_offset + (int)(r % S);
+        float c[8], s[8], a[8], b[8], oa[8], ob[8];
+        load8<float>(cos_tab + (long long)pos * half + i, c);
+        load8<float>(sin_tab + (long long)pos * half + i, s);
+        T* p = x + r * ld + (long long)h * hd + i;
+        load8<T>(p, a);
+        load8<T>(p + half, b);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float cj = c[j], sj = inverse ? -s[j] : s[j];
+            if (sizeof(T) == 2) {
+                cj = bf2f(f2bf(cj)); sj = bf2f(f2bf(sj));
+                oa[j] = bf2f(f2bf(a[j] * cj)) + bf2f(f2bf(-b[j] * sj));
+                ob[j] = bf2f(f2bf(b[j] * cj)) + bf2f(f2bf(a[j] * sj));
+            } else {
+                oa[j] = a[j] * cj + (-b[j]) * sj;
+                ob[j] = b[j] * cj + a[j] * sj;
+            }
+        }
+        store8<T>(p, oa);
+        store8<T>(p + half, ob);
+    }
+}
+
 extern "C" int egomi_rope(void* x, const float* cos_tab, const float* sin_tab, int64_t rows, int S, int pos_offset, int H, int hd,
                           int64_t ld, int inverse, int dtype, egomi_stream_t stream) {
     if (!x || !cos_tab || !sin_tab) return EGOMI_E_BADARG;
     if (rows <= 0 || S <= 0 || H <= 0 || hd <= 0 || (hd & 1) || ld < (int64_t)H * hd || pos_offset < 0) return EGOMI_E_SHAPE;
+    const int esz = dtype == EGOMI_F32 ? 4 : 2;
+    if ((hd / 2) % 8 == 0 && ld % 8 == 0 && ((uintptr_t)x % 16) == 0 && ((hd / 2) * esz) % 16 == 0) {
+        const long long tv = rows * H * (hd / 16);
+        const int gv = (int)((tv + 255) / 256 < 16384 ? (tv + 255) / 256 : 16384);
+        EGOMI_DISPATCH_DTYPE(dtype, EGOMI_LAUNCH(rope_vec8_kernel<T>, dim3(gv), dim3(256), 0, (hipStream_t)stream,
+                                                 (T*)x, cos_tab, sin_tab, rows, S, pos_offset, H, hd, ld, inverse));
+        return egomi_launch_status();
+    }
     const long long total = rows * H * (hd / 2);
     const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
     EGOMI_DISPATCH_DTYPE(dtype, EGOMI_LAUNCH(rope_kernel<T>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
@@ -696,5 +738,26 @@ extern "C" int egomi_linear_smallk(const void* x, int x_dtype, const void* w, co
     else if (x_dtype == EGOMI_BF16 && dtype == EGOMI_BF16)
         EGOMI_LAUNCH((linear_smallk_kernel<bf16_t, bf16_t>), g, bl, 0, s, (const bf16_t*)x, (const bf16_t*)w, (const bf16_t*)b, (bf16_t*)y, (long long)R, N, K, act);
     else return EGOMI_E_BADARG;
+    return egomi_launch_status();
+}
+
+// column sums: out[c] (+)= sum_r x[r, c]   (bias gradients of the projector, pointllm.py:67-81 backward)
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* x, long long R, int C, long long ld, float* out, int rows_per_block) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const long long r0 = (long long)blockIdx.y * rows_per_block;
+    long long r1 = r0 + rows_per_block;
+    r1 = r1 < R ? r1 : R;
+    float acc = 0.f;
+    for (long long r = r0; r < r1; ++r) acc += Cvt<T>::ld(x + r * ld + c);
+    atomicAdd(out + c, acc);
+}
+extern "C" int egomi_colsum(const void* x, int64_t R, int C, int64_t ld, float* out, int dtype, egomi_stream_t stream) {
+    if (!x || !out) return EGOMI_E_BADARG;
+    if (R <= 0 || C <= 0 || ld < C) return EGOMI_E_SHAPE;
+    const int rpb = 128;
+    dim3 grid((C + 255) / 256, (unsigned)((R + rpb - 1) / rpb));
+    EGOMI_DISPATCH_DTYPE(dtype, EGOMI_LAUNCH(colsum_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, (const T*)x, (long long)R, C, (long long)ld, out, rpb));
     return egomi_launch_status();
 }

@@ -266,8 +266,7 @@ class Engine:
             ops.mm(h, w[p + "self_attn.q_proj.weight"], out=qkv[:, :d])
             ops.mm(h, w[p + "self_attn.k_proj.weight"], out=qkv[:, d:2 * d])
             ops.mm(h, w[p + "self_attn.v_proj.weight"], out=qkv[:, 2 * d:])
-            ops.rope_(qkv[:, :d], self.cos, self.sin, M, S, past, H, hd, 3 * d)
-            ops.rope_(qkv[:, d:2 * d], self.cos, self.sin, M, S, past, H, hd, 3 * d)
+            ops.rope_(qkv, self.cos, self.sin, M, S, past, 2 * H, hd, 3 * d)          # q and k heads are adjacent columns
             if kv_cache is None:
                 lse = None
                 if fused:
@@ -345,20 +344,24 @@ class Engine:
         return ops.mm(dY, self.w[name], out=out, b_layout=1, residual=residual)
 
     def _wgrad(self, name, dY, X):
-        """main_grad[name] (fp32 [N,K]) += dY^T [N,M] . X [M,K]"""
-        if name in self.trainable:
-            ops.mm(dY, X, out=self.grad_buffer(name), a_layout=1, b_layout=1, accumulate=True)
+        """main_grad[name] (fp32 [N,K]) += dY^T [N,M] . X [M,K].  bf16: both operands are transposed
+        into zero-padded [*, M64] buffers so the product runs K-contiguous on the tuned kernel."""
+        if name not in self.trainable:
+            return
+        g = self.grad_buffer(name)
+        Mr, N = dY.shape
+        K = X.shape[1]
+        if self.dtype == torch.bfloat16 and Mr >= 256 and N * K >= 128 * 128:
+            Mp = (Mr + 63) // 64 * 64
+            dYt = ops.transpose(dY, ldo=Mp, out=self.ws.get(f"wg_dYt_{N}_{Mp}", (N, Mp), self.dtype))
+            Xt = ops.transpose(X, ldo=Mp, out=self.ws.get(f"wg_Xt_{K}_{Mp}", (K, Mp), self.dtype))
+            ops.mm(dYt, Xt, out=g, accumulate=True)
+        else:
+            ops.mm(dY, X, out=g, a_layout=1, b_layout=1, accumulate=True)
 
     def _bgrad(self, name, dY):
         if name in self.trainable:
-            ones = self.ws.get("ones_col", (dY.shape[0], 8), dY.dtype)
-            if not getattr(self, "_ones_ready", None) == dY.shape[0]:
-                ones.fill_(1.0)
-                self._ones_ready = dY.shape[0]
-            g = self.grad_buffer(name)
-            tmp = self.ws.get("bgrad_tmp", (dY.shape[1], 8), torch.float32)
-            ops.mm(dY, ones, out=tmp, a_layout=1, b_layout=1)          # column sums on the MFMA path
-            g += tmp[:, 0]
+            ops.colsum_(dY, self.grad_buffer(name))
 
     def backward_hidden(self, d_hn):
         """d_hn: gradient w.r.t. the final-normed hidden [M,d].  Accumulates fp32 main_grad of the
@@ -398,8 +401,7 @@ class Engine:
                              causal=True, key_mask=ctx["key_mask"])
             else:
                 self._attention_bwd(qkv, lc["P"], d_ao, dqkv, B, S, H, hd, scale)
-            ops.rope_(dqkv[:, :d], self.cos, self.sin, M, S, 0, H, hd, 3 * d, inverse=True)
-            ops.rope_(dqkv[:, d:2 * d], self.cos, self.sin, M, S, 0, H, hd, 3 * d, inverse=True)
+            ops.rope_(dqkv, self.cos, self.sin, M, S, 0, 2 * H, hd, 3 * d, inverse=True)
             d_h = self._dgrad(dqkv[:, :d], p + "self_attn.q_proj.weight", ws.get("d_h", (M, d), T))
             self._dgrad(dqkv[:, d:2 * d], p + "self_attn.k_proj.weight", d_h, residual=d_h)
             self._dgrad(dqkv[:, 2 * d:], p + "self_attn.v_proj.weight", d_h, residual=d_h)

@@ -313,6 +313,13 @@ def add(a, b, out=None):
     return out
 
 
+def colsum_(x, out):
+    """out (fp32 [C]) += column sums of x [R,C]."""
+    R, C = x.shape
+    call("egomi_colsum", P(x), c_i64(R), c_i(C), c_i64(_ld(x)), P(out), c_i(dt(x.dtype)), S())
+    return out
+
+
 def group_max(x, BG, M, C, concat=False, out=None):
     if out is None:
         out = torch.empty((BG * M, 2 * C) if concat else (BG, C), dtype=x.dtype, device=x.device)

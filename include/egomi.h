@@ -214,6 +214,8 @@ int egomi_adamw(float* master, void* model_copy, const float* grad, float* m, fl
 int egomi_transpose(const void* in, int R, int C, int64_t ldi, void* out, int64_t ldo, int dtype, egomi_stream_t stream);
 int egomi_cast(const void* in, int in_dtype, void* out, int out_dtype, int64_t n, egomi_stream_t stream);
 int egomi_add(const void* a, const void* b, void* out, int64_t n, int dtype, egomi_stream_t stream);
+/* out[c] (fp32, caller-initialised) += sum_r x[r,c]: bias gradients (backward of nn.Linear bias, model/pointllm.py:67-81) */
+int egomi_colsum(const void* x, int64_t R, int C, int64_t ld, float* out, int dtype, egomi_stream_t stream);
 
 /* A6 helpers.  group_max: x [BG, M, C] -> out [BG, C] (concat=0) or [BG*M, 2C] = [group max | x]
  * (concat=1).  replaces torch.max / cat / expand at pointbert/dvae.py:216-219.

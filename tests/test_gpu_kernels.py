@@ -358,3 +358,11 @@ def test_fused_attention_backward(ops, B, S, H, causal, masked):
         got, want = dqkv[:, i * d:(i + 1) * d], g[:, i * d:(i + 1) * d]
         err = (got.float().cpu() - want).abs().max().item()
         assert err <= 3e-2 * (want.abs().max().item() + 1e-9), (name, err, want.abs().max().item())
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_colsum(ops, dtype):
+    x = rnd(333, 517, dtype=dtype)
+    out = torch.ones(517, dtype=torch.float32, device="cuda")
+    ops.colsum_(x.cuda(), out)
+    close(out, x.float().sum(0) + 1.0, 1e-4 if dtype == torch.float32 else 1e-3)
