@@ -644,9 +644,38 @@ __global__ __launch_bounds__(256) void transpose_kernel(const T* in, int R, int 
     }
 }
 
+// bf16 fast path: 64x64 tiles, 16-B global loads and stores on both sides, 2-B gathers only inside LDS
+__global__ __launch_bounds__(256) void transpose_bf16_vec_kernel(const bf16_t* in, int R, int C, long long ldi, bf16_t* out, long long ldo) {
+    __shared__ __attribute__((aligned(16))) bf16_t tile[64][72];
+    const int c0 = blockIdx.x * 64, r0 = blockIdx.y * 64;
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = (t >> 3) + 32 * i, cc = (t & 7) * 8;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (r0 + r < R && c0 + cc < C) v = *reinterpret_cast<const u32x4*>(in + (long long)(r0 + r) * ldi + c0 + cc);   // C % 8 == 0
+        *reinterpret_cast<u32x4*>(&tile[r][cc]) = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int oc = (t >> 3) + 32 * i, rc = (t & 7) * 8;          // output row = input column c0+oc
+        if (c0 + oc >= C || r0 + rc >= ldo) continue;
+        u32x4 v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = (uint32_t)tile[rc + 2 * j][oc] | ((uint32_t)tile[rc + 2 * j + 1][oc] << 16);   // rows >= R were zero-filled
+        *reinterpret_cast<u32x4*>(out + (long long)(c0 + oc) * ldo + r0 + rc) = v;                                     // ldo % 8 == 0
+    }
+}
+
 extern "C" int egomi_transpose(const void* in, int R, int C, int64_t ldi, void* out, int64_t ldo, int dtype, egomi_stream_t stream) {
     if (!in || !out) return EGOMI_E_BADARG;
     if (R <= 0 || C <= 0 || ldi < C || ldo < R) return EGOMI_E_SHAPE;
+    if (dtype == EGOMI_BF16 && C % 8 == 0 && ldi % 8 == 0 && ldo % 8 == 0 && ((uintptr_t)in % 16) == 0 && ((uintptr_t)out % 16) == 0) {
+        dim3 g((C + 63) / 64, (unsigned)((ldo + 63) / 64));
+        EGOMI_LAUNCH(transpose_bf16_vec_kernel, g, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)in, R, C, (long long)ldi, (bf16_t*)out, (long long)ldo);
+        return egomi_launch_status();
+    }
     dim3 grid((C + 31) / 32, (unsigned)((ldo + 31) / 32));
     EGOMI_DISPATCH_DTYPE(dtype, EGOMI_LAUNCH(transpose_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, (const T*)in, R, C, ldi, (T*)out, ldo));
     return egomi_launch_status();

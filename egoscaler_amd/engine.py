@@ -81,11 +81,20 @@ class Engine:
         if self.dtype == torch.bfloat16:
             for l in range(lm.num_hidden_layers):
                 for nm in self.layer_param_names(l):
-                    if nm not in self.trainable and w[nm].dim() == 2:
-                        self.wT[nm] = ops.transpose(w[nm])
+                    if w[nm].dim() == 2:
+                        self.wT[nm] = ops.transpose(w[nm])     # trainable ones are refreshed by after_weights_update()
         cos, sin = ops.rope_tables(lm.max_position_embeddings, lm.head_dim, lm.rope_theta)
         self.cos, self.sin = cos.to(self.device), sin.to(self.device)
         self.prepared = True
+
+    def after_weights_update(self):
+        """Called by the optimizer after a step: the resident W^T of TRAINABLE decoder weights must
+        follow the new values (a 2-byte transpose pass per weight; frozen ones never change)."""
+        if not self.prepared:
+            return
+        for nm, wt in self.wT.items():
+            if nm in self.trainable:
+                ops.transpose(self.w[nm], out=wt)
 
     def set_trainable(self, names):
         self.trainable = {n: True for n in names}
@@ -351,7 +360,7 @@ class Engine:
         g = self.grad_buffer(name)
         Mr, N = dY.shape
         K = X.shape[1]
-        if self.dtype == torch.bfloat16 and Mr >= 256 and N * K >= 128 * 128:
+        if self.dtype == torch.bfloat16 and Mr >= 128 and N * K >= 128 * 128:
             Mp = (Mr + 63) // 64 * 64
             dYt = ops.transpose(dY, ldo=Mp, out=self.ws.get(f"wg_dYt_{N}_{Mp}", (N, Mp), self.dtype))
             Xt = ops.transpose(X, ldo=Mp, out=self.ws.get(f"wg_Xt_{K}_{Mp}", (K, Mp), self.dtype))

@@ -27,6 +27,7 @@ class EgoAdamW:
             p = st["p"]
             copy = None if p.dtype == torch.float32 else p.data
             ops.adamw(st["master"], copy, g, st["m"], st["v"], lr, self.betas[0], self.betas[1], self.eps, self.wd, self.t, grad_scale)
+        eng.after_weights_update()
 
     def zero_grad(self):
         self.model.engine.zero_grad()
