@@ -1,0 +1,125 @@
+"""Cached greedy decoding (A13) with static buffers and optional hipGraph capture.
+
+Reference behaviour: model_arch.py:77-108 -> HF generate: one prefill (point encoder + splice,
+pointllm.py:112-171) that fills the KV cache, then single-token steps (pointllm.py:255-275).
+Here the prefill is Engine.forward_hidden with a kv_sink; each later step runs
+  embed -> 32 x {rmsnorm, q/k/v GEMMs, RoPE(pos), kv_append, attn_decode, o_proj, rmsnorm, SwiGLU MLP}
+  -> final norm -> lm_head -> argmax
+on static buffers.  Every length is a launch argument, so T steps are captured into ONE hipGraph
+(BASELINE.json config 5) and replayed with a single launch; token ids never leave the device.
+"""
+import ctypes
+
+import torch
+
+from . import ops
+from ._lib import c_p, c_i, c_f, c_i64, call
+from .ops import P, S, dt
+
+
+def kv_append(k, v, ld, kc, vc, B, Sq, H, hd, Smax, pos0):
+    call("egomi_kv_append", P(k), P(v), c_i64(ld), P(kc), P(vc), c_i(B), c_i(Sq), c_i(H), c_i(hd), c_i(Smax), c_i(pos0), c_i(dt(k.dtype)), S())
+
+
+def attn_decode(q, ld_q, kc, vc, key_mask, out, B, H, hd, Smax, T_len, scale):
+    call("egomi_attn_decode", P(q), c_i64(ld_q), P(kc), P(vc), P(key_mask), c_i64(key_mask.stride(0) if key_mask is not None else 0),
+         P(out), c_i64(out.stride(0)), c_i(B), c_i(H), c_i(hd), c_i(Smax), c_i(T_len), c_f(scale), c_i(dt(q.dtype)), S())
+
+
+def argmax_rows(logits, ids, seq=None, pos=0):
+    B, V = logits.shape
+    call("egomi_argmax_rows", P(logits), c_i64(logits.stride(0)), c_i(B), c_i(V), P(ids), P(seq), c_i64(seq.stride(0) if seq is not None else 0),
+         c_i(pos), c_i(dt(logits.dtype)), S())
+
+
+class Decoder:
+    def __init__(self, engine, B, max_len):
+        self.eng, self.B, self.Smax = engine, B, max_len
+        lm = engine.dims.lm
+        L, H, hd, d, Fd, V = lm.num_hidden_layers, lm.num_attention_heads, lm.head_dim, lm.hidden_size, lm.intermediate_size, lm.vocab_size
+        T, dev = engine.dtype, engine.device
+        self.kc = torch.zeros(L, B, H, max_len, hd, dtype=T, device=dev)
+        self.vc = torch.zeros(L, B, H, max_len, hd, dtype=T, device=dev)
+        z = lambda *s, dtype=T: torch.zeros(*s, dtype=dtype, device=dev)
+        self.x, self.h, self.qkv, self.ao, self.x_mid, self.h2 = z(B, d), z(B, d), z(B, 3 * d), z(B, d), z(B, d), z(B, d)
+        self.gu, self.act, self.x_out, self.hn, self.lg = z(B, 2 * Fd), z(B, Fd), z(B, d), z(B, d), z(B, V)
+        self.tok = z(B, 1, dtype=torch.int64)
+        self.seq = None
+        self.mask = None
+        self.pos = 0
+
+    # -- prefill -------------------------------------------------------------------------------------
+    def _sink(self, l, qkv, B, Sq):
+        lm = self.eng.dims.lm
+        H, hd, d = lm.num_attention_heads, lm.head_dim, lm.hidden_size
+        kv_append(qkv[:, d:2 * d], qkv[:, 2 * d:], qkv.stride(0), self.kc[l], self.vc[l], B, Sq, H, hd, self.Smax, 0)
+
+    def prefill(self, input_ids, attention_mask, point_clouds, fps_start, total_new):
+        B, S0 = input_ids.shape
+        dev = self.eng.device
+        mask = torch.ones(B, S0, dtype=torch.bool, device=dev) if attention_mask is None else attention_mask.to(dev).bool()
+        self.mask = torch.cat([mask, torch.ones(B, self.Smax - S0, dtype=torch.bool, device=dev)], 1).to(torch.uint8).contiguous()
+        hn = self.eng.forward_hidden(input_ids, mask, point_clouds, fps_start, save=False, kv_sink=self._sink)
+        self.pos = S0
+        self.seq = torch.zeros(B, S0 + total_new, dtype=torch.int64, device=dev)
+        self.seq[:, :S0] = input_ids
+        last = hn.view(B, S0, -1)[:, -1].contiguous()
+        ops.mm(last, self.eng.w["lm_head.weight"], out=self.lg)
+        return self.lg
+
+    # -- one decode step on static buffers: consumes self.tok, leaves logits in self.lg ---------------------
+    def step(self, pos):
+        eng = self.eng
+        w, lm = eng.w, eng.dims.lm
+        B, d, Fd, H, hd, L = self.B, lm.hidden_size, lm.intermediate_size, lm.num_attention_heads, lm.head_dim, lm.num_hidden_layers
+        ops.embed_splice(self.tok, w["model.embed_tokens.weight"], None, None, eng.dims.pb.point_token_len, out=self.x.view(B, 1, d))
+        x = self.x
+        scale = hd ** -0.5
+        for l in range(L):
+            p = f"model.layers.{l}."
+            ops.rmsnorm(x, w[p + "input_layernorm.weight"], lm.rms_norm_eps, out=self.h)
+            ops.mm(self.h, w[p + "self_attn.q_proj.weight"], out=self.qkv[:, :d])
+            ops.mm(self.h, w[p + "self_attn.k_proj.weight"], out=self.qkv[:, d:2 * d])
+            ops.mm(self.h, w[p + "self_attn.v_proj.weight"], out=self.qkv[:, 2 * d:])
+            ops.rope_(self.qkv, eng.cos, eng.sin, B, 1, pos, 2 * H, hd, 3 * d)
+            kv_append(self.qkv[:, d:2 * d], self.qkv[:, 2 * d:], 3 * d, self.kc[l], self.vc[l], B, 1, H, hd, self.Smax, pos)
+            attn_decode(self.qkv, 3 * d, self.kc[l], self.vc[l], self.mask, self.ao, B, H, hd, self.Smax, pos + 1, scale)
+            ops.mm(self.ao, w[p + "self_attn.o_proj.weight"], out=self.x_mid, residual=x)
+            ops.rmsnorm(self.x_mid, w[p + "post_attention_layernorm.weight"], lm.rms_norm_eps, out=self.h2)
+            ops.mm(self.h2, w[p + "mlp.gate_proj.weight"], out=self.gu[:, :Fd])
+            ops.mm(self.h2, w[p + "mlp.up_proj.weight"], out=self.gu[:, Fd:])
+            ops.swiglu(self.gu[:, :Fd], self.gu[:, Fd:], self.act)
+            ops.mm(self.act, w[p + "mlp.down_proj.weight"], out=x, residual=self.x_mid)     # x is not an input of this product
+        ops.rmsnorm(x, w["model.norm.weight"], lm.rms_norm_eps, out=self.hn)
+        ops.mm(self.hn, w["lm_head.weight"], out=self.lg)
+
+    def greedy(self, T_new, use_graph=True, keep_scores=True):
+        """After prefill(): T_new greedy tokens.  Returns (sequences [B,S0+T], scores list or None)."""
+        S0 = self.pos
+        scores = [] if keep_scores else None
+        if not use_graph:
+            for t in range(T_new):
+                if keep_scores:
+                    scores.append(self.lg.float().clone())
+                argmax_rows(self.lg, self.tok.view(-1), self.seq, S0 + t)
+                if t + 1 < T_new:
+                    self.step(S0 + t)
+            self.pos = S0 + T_new
+            return self.seq, scores
+        sc_buf = torch.zeros(T_new, self.B, self.lg.shape[1], dtype=torch.float32, device=self.eng.device) if keep_scores else None
+        g = torch.cuda.CUDAGraph()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            with torch.cuda.graph(g, stream=side):
+                for t in range(T_new):
+                    if keep_scores:
+                        ops.cast(self.lg, torch.float32, out=sc_buf[t])
+                    argmax_rows(self.lg, self.tok.view(-1), self.seq, S0 + t)
+                    if t + 1 < T_new:
+                        self.step(S0 + t)
+        torch.cuda.current_stream().wait_stream(side)
+        g.replay()
+        self.graph = g
+        self.pos = S0 + T_new
+        return self.seq, ([sc_buf[t] for t in range(T_new)] if keep_scores else None)

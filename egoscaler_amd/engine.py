@@ -198,18 +198,22 @@ class Engine:
         return out
 
     # ------------------------------------------------------------------------------------ forward
-    def forward_hidden(self, input_ids, attention_mask, point_clouds, fps_start, save=True, kv_cache=None):
-        """-> final-normed hidden [B*S, d]; fills self.ctx for backward when save=True."""
+    def forward_hidden(self, input_ids, attention_mask, point_clouds, fps_start, save=True, kv_sink=None):
+        """-> final-normed hidden [B*S, d]; fills self.ctx for backward when save=True.
+        kv_sink(layer, qkv, B, S): optional prefill hook that receives the post-RoPE q|k|v buffer of every
+        layer (decode.Decoder copies k, v into its static cache)."""
         if not self.prepared:
             self.prepare()
         w, dims, T, ws = self.w, self.dims, self.dtype, self.ws
         lm, pb, tok = dims.lm, dims.pb, dims.tok
+        if input_ids.dtype != torch.int64 or not input_ids.is_contiguous():
+            input_ids = input_ids.to(torch.int64).contiguous()      # kernels index ids as a dense [B,S] int64 array
         B, S = input_ids.shape
         d, Fd, H, hd, L = lm.hidden_size, lm.intermediate_size, lm.num_attention_heads, lm.head_dim, lm.num_hidden_layers
         M = B * S
         Pn = pb.point_token_len
         ctx = {"B": B, "S": S, "ids": input_ids, "layers": []} if save else None
-        past = 0 if kv_cache is None else kv_cache["len"]
+        past = 0
         # ---- point branch (pointllm.py:112-129): only when S != 1 (prefill / training)
         feats_proj, start_pos = None, None
         if point_clouds is not None and S != 1:
@@ -251,7 +255,7 @@ class Engine:
         if attention_mask is not None:
             key_mask = attention_mask.to(device=self.device, dtype=torch.uint8).contiguous()
         scale = hd ** -0.5
-        fused = self.use_fused_attention and T == torch.bfloat16 and hd == 128 and kv_cache is None
+        fused = self.use_fused_attention and T == torch.bfloat16 and hd == 128
         for l in range(L):
             p = f"model.layers.{l}."
             if save:
@@ -276,18 +280,16 @@ class Engine:
             ops.mm(h, w[p + "self_attn.k_proj.weight"], out=qkv[:, d:2 * d])
             ops.mm(h, w[p + "self_attn.v_proj.weight"], out=qkv[:, 2 * d:])
             ops.rope_(qkv, self.cos, self.sin, M, S, past, 2 * H, hd, 3 * d)          # q and k heads are adjacent columns
-            if kv_cache is None:
-                lse = None
-                if fused:
-                    # fused flash-style kernel: scores never reach HBM; LSE (and the output) are kept for backward
-                    Pm = None
-                    lse = torch.empty(B, H, S, dtype=torch.float32, device=self.device) if save else ws.get("att_lse", (B, H, S), torch.float32)
-                    ops.attn_fwd(qkv, B, S, H, hd, scale, ao, lse, causal=True, key_mask=key_mask)
-                else:
-                    Pm = self._attention("lm", qkv, B, S, H, hd, ao, True, key_mask, scale, save)
-            else:
+            if kv_sink is not None:
+                kv_sink(l, qkv, B, S)
+            lse = None
+            if fused:
+                # fused flash-style kernel: scores never reach HBM; LSE (and the output) are kept for backward
                 Pm = None
-                self._attention_cached(l, qkv, B, S, H, hd, ao, key_mask, scale, kv_cache)
+                lse = torch.empty(B, H, S, dtype=torch.float32, device=self.device) if save else ws.get("att_lse", (B, H, S), torch.float32)
+                ops.attn_fwd(qkv, B, S, H, hd, scale, ao, lse, causal=True, key_mask=key_mask)
+            else:
+                Pm = self._attention("lm", qkv, B, S, H, hd, ao, True, key_mask, scale, save)
             ops.mm(ao, w[p + "self_attn.o_proj.weight"], out=x_mid, residual=x)
             ops.rmsnorm(x_mid, w[p + "post_attention_layernorm.weight"], lm.rms_norm_eps, rstd=rstd2, out=h2)
             ops.mm(h2, w[p + "mlp.gate_proj.weight"], out=gu[:, :Fd])
@@ -298,8 +300,6 @@ class Engine:
                 lc.update(P=Pm, lse=lse, x_mid=x_mid, h=h, ao=ao, h2=h2, act=act)
                 ctx["layers"].append(lc)
             x = x_out
-        if kv_cache is not None:
-            kv_cache["len"] = past + S
         rstd_f = torch.empty(M, dtype=torch.float32, device=self.device) if save else None
         hn = torch.empty(M, d, dtype=T, device=self.device)
         ops.rmsnorm(x, w["model.norm.weight"], lm.rms_norm_eps, rstd=rstd_f, out=hn)
@@ -307,33 +307,6 @@ class Engine:
             ctx.update(x_last=x, rstd_f=rstd_f, hn=hn, key_mask=key_mask)
             self.ctx = ctx
         return hn
-
-    def _attention_cached(self, l, qkv, B, S, H, hd, out, key_mask, scale, cache):
-        """Prefill (S>1) fills the cache; decode (S==1) attends against it (pointllm.py:255-275)."""
-        d = H * hd
-        past, Smax = cache["len"], cache["max"]
-        kc, vc = cache["k"][l], cache["v"][l]                     # [B, Smax, d]
-        kc[:, past:past + S] = qkv[:, d:2 * d].view(B, S, d)
-        vc[:, past:past + S] = qkv[:, 2 * d:].view(B, S, d)
-        Tk = past + S
-        q = qkv[:, :d]
-        sc = self.ws.get("att_scores_c", (B * H, S, Tk), torch.float32)
-        ops.gemm_raw(q, kc, sc, S, Tk, hd, 3 * d, d, Tk, 0, 0, alpha=scale, batch=B * H, batch_inner=H,
-                     strides=(S * 3 * d, hd, Smax * d, hd, H * S * Tk, S * Tk))
-        Pm = self.ws.get("att_P_c", (B * H, S, Tk), self.dtype)
-        km = None
-        if key_mask is not None:
-            km = key_mask[:, :Tk].contiguous()
-        ops.softmax(sc, B * H, H, S, Tk, Pm, causal=True, q_offset=past, key_mask=km)
-        ops.gemm_raw(Pm, vc, out, S, hd, Tk, Tk, d, d, 0, 1, batch=B * H, batch_inner=H,
-                     strides=(H * S * Tk, S * Tk, Smax * d, hd, S * d, hd))
-
-    def new_kv_cache(self, B, max_len):
-        lm = self.dims.lm
-        L, d = lm.num_hidden_layers, lm.hidden_size
-        return {"len": 0, "max": max_len,
-                "k": torch.zeros(L, B, max_len, d, dtype=self.dtype, device=self.device),
-                "v": torch.zeros(L, B, max_len, d, dtype=self.dtype, device=self.device)}
 
     def logits(self, hn, rows=None):
         """lm_head (pointllm.py:227-228).  hn [M,d] -> [M,V]."""

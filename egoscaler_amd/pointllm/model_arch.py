@@ -359,25 +359,26 @@ class TrajPointLLMForCausalLM(nn.Module):
         reference's cache bug).  do_sample=False is greedy arg-max and is what parity pins."""
         if num_return_sequences != 1 or repetition_penalty != 1.0:
             raise NotImplementedError("num_return_sequences != 1 / repetition_penalty are not built")
+        from ..decode import Decoder, argmax_rows
         eng = self.engine
         dev = eng.device
         ids = input_ids.to(dev)
         B, S0 = ids.shape
-        mask = torch.ones(B, S0, dtype=torch.bool, device=dev) if attention_mask is None else attention_mask.to(dev).bool()
         if fps_start is None and point_clouds is not None:
             fps_start = torch.randint(0, point_clouds.shape[1], (B,), dtype=torch.long)
         T = int(max_length)
-        cache = eng.new_kv_cache(B, S0 + T)
-        full_mask = torch.cat([mask, torch.ones(B, T, dtype=torch.bool, device=dev)], 1)
-        hn = eng.forward_hidden(ids, full_mask[:, :S0], point_clouds, fps_start, save=False, kv_cache=cache)
-        d = hn.shape[1]
-        last = hn.view(B, S0, d)[:, -1].contiguous()
+        dec = Decoder(eng, B, S0 + T)
+        lg = dec.prefill(ids, attention_mask, point_clouds, fps_start, T)
+        if not do_sample and eos_token_id is None:
+            # greedy, fixed length: all T steps captured into one hipGraph (use_graph) and replayed
+            seq, scores = dec.greedy(T, use_graph=kwargs.get("use_graph", True))
+            return GenerateOutput(sequences=seq, scores=tuple(scores))
         seq, scores = ids, []
         done = torch.zeros(B, dtype=torch.bool, device=dev)
         for t in range(T):
-            lg = eng.logits(last).float()
+            lgf = lg.float()
             if do_sample:
-                s = lg / max(float(temperature or 1.0), 1e-6)
+                s = lgf / max(float(temperature or 1.0), 1e-6)
                 if top_k:
                     kth = torch.topk(s, min(int(top_k), s.shape[-1]), dim=-1)[0][:, -1:]
                     s = s.masked_fill(s < kth, float("-inf"))
@@ -390,15 +391,17 @@ class TrajPointLLMForCausalLM(nn.Module):
                 scores.append(s)
                 nxt = torch.multinomial(s.softmax(-1), 1)
             else:
-                scores.append(lg)
-                nxt = lg.argmax(-1, keepdim=True)
+                scores.append(lgf.clone())
+                nxt = lgf.argmax(-1, keepdim=True)
             if eos_token_id is not None:
                 nxt = torch.where(done[:, None], torch.full_like(nxt, pad_token_id if pad_token_id is not None else eos_token_id), nxt)
                 done = done | (nxt[:, 0] == eos_token_id)
             seq = torch.cat([seq, nxt], 1)
             if t + 1 == T or (eos_token_id is not None and bool(done.all())):
                 break
-            last = eng.forward_hidden(nxt, full_mask[:, :S0 + t + 1], None, None, save=False, kv_cache=cache)
+            dec.tok.copy_(nxt)
+            dec.step(S0 + t)
+            lg = dec.lg
         return GenerateOutput(sequences=seq, scores=tuple(scores))
 
     def train(self, mode: bool = True):

@@ -141,6 +141,24 @@ int egomi_attn_fwd(const egomi_attn_desc* desc, egomi_stream_t stream);
 int egomi_attn_bwd(const egomi_attn_desc* desc, egomi_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * A13  cached decoding.  replaces the past_key_values branch of HF LlamaAttention.forward
+ * (modeling_llama.py:243-281) and the greedy step of generate (models/pointllm/model_arch.py:94-108,
+ * pointllm/model/pointllm.py:255-275).  KV cache layout [B, H, Smax, hd] per layer (contiguous
+ * per-(batch, head) streams).  No entry point reads a length from device memory: every step's
+ * constants are arguments, so a whole multi-step decode can be captured into one hipGraph.
+ *   kv_append : k, v rows [B*S, H*hd] (row stride ld) -> cache[b, h, pos0+s, :]
+ *   attn_decode: q [B, H*hd] against keys [0, T_len) -> out [B, H*hd]; key_mask [B, >=T_len] u8 or NULL
+ *   argmax_rows: ids[b] = argmax logits[b, :] (lowest index on ties); seq[b*ld_seq + pos] = ids[b]
+ */
+int egomi_kv_append(const void* k, const void* v, int64_t ld, void* kcache, void* vcache, int B, int S, int H, int hd, int Smax,
+                    int pos0, int dtype, egomi_stream_t stream);
+int egomi_attn_decode(const void* q, int64_t ld_q, const void* kcache, const void* vcache, const uint8_t* key_mask, int64_t ld_mask,
+                      void* out, int64_t ld_o, int B, int H, int hd, int Smax, int T_len, float scale, int dtype,
+                      egomi_stream_t stream);
+int egomi_argmax_rows(const void* logits, int64_t ld, int B, int V, int64_t* ids, int64_t* seq, int64_t ld_seq, int pos, int dtype,
+                      egomi_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Row / elementwise kernels (HBM-bound).  `dtype` is the activation/parameter dtype T.
  */
 /* LayerNorm forward with optional fused pre-add: s = x (+ add); y = (s-mean)*rstd*w + b; sum_out = s

@@ -1,0 +1,94 @@
+#!/usr/bin/env python3
+"""BASELINE.json config 5: inference-only greedy decode, bs=256, prefill S0~=540 once, then 32
+single-token steps captured into ONE hipGraph.  Reports tokens/s and achieved HBM GB/s against the
+algorithmic bytes of SURVEY.md §8d ("Roofline - decode": per step 2*P_llm bytes of weights + the K/V
+rows read, B*S_ctx*512 KiB).  GPU box only:  python tools/bench_decode.py [--batch 256] [--steps 32]"""
+import argparse, json, os, sys, time, types
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from egoscaler_amd import synth
+from egoscaler_amd.config import dims_7b
+from egoscaler_amd.decode import Decoder
+from egoscaler_amd.pointllm import TrajPointLLMForCausalLM
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--batch", type=int, default=256)
+ap.add_argument("--steps", type=int, default=32)
+ap.add_argument("--prefill-chunk", type=int, default=16, help="prompts are prefilled in chunks of this many samples")
+ap.add_argument("--layers", type=int, default=None)
+a = ap.parse_args()
+dims = dims_7b()
+if a.layers:
+    dims.lm.num_hidden_layers = a.layers
+dev = torch.device("cuda")
+args = types.SimpleNamespace(unfreeze_pc_encoder=False, unfreeze_language_model=False, num_bins=256, model_name=None)
+m = TrajPointLLMForCausalLM(args, dims, None, device=dev, dtype=torch.bfloat16)
+g = torch.Generator(device=dev).manual_seed(7)
+with torch.no_grad():
+    for n, p in list(m.named_parameters()) + list(m.named_buffers()):
+        leaf = n.rsplit(".", 1)[-1]
+        if leaf == "num_batches_tracked":
+            continue
+        if leaf == "running_var" or (leaf == "weight" and p.dim() == 1):
+            p.fill_(1.0)
+        elif leaf == "running_mean":
+            p.zero_()
+        else:
+            fan = p[0].numel() if p.dim() > 1 else p.numel()
+            for r0 in range(0, p.shape[0], 8192):
+                blk = p[r0:r0 + 8192]
+                blk.copy_(torch.empty(blk.shape, dtype=torch.float32, device=dev).normal_(0, 0.02 if fan >= 1024 else min(0.35, fan ** -0.5), generator=g))
+m.eval()
+eng = m.engine
+B, T = a.batch, a.steps
+toks, masks, Lp = synth.synth_batch(dims, 1, text_len=16, num_steps=20, max_traj_token=160)
+S0 = Lp
+ids = toks[:, :S0].repeat(B, 1).to(dev)
+pc = synth.synth_cloud(dims, 0)[None].to(dev)
+dec = Decoder(eng, B, S0 + T)
+# prefill in chunks (the prompt pass is not what config 5 times); each chunk fills its slice of the cache
+t0 = time.perf_counter()
+C = a.prefill_chunk
+for b0 in range(0, B, C):
+    sub = Decoder.__new__(Decoder)
+    sub.eng, sub.B, sub.Smax = eng, C, S0 + T
+    sub.kc, sub.vc = dec.kc[:, b0:b0 + C], dec.vc[:, b0:b0 + C]
+    def sink(l, qkv, Bc, Sq, sub=sub):
+        from egoscaler_amd.decode import kv_append
+        d = eng.dims.lm.hidden_size
+        # slices of the big cache are not contiguous over batch: append sample by sample
+        for i in range(Bc):
+            kv_append(qkv[i * Sq:(i + 1) * Sq, d:2 * d], qkv[i * Sq:(i + 1) * Sq, 2 * d:], qkv.stride(0), sub.kc[l, i], sub.vc[l, i], 1, Sq,
+                      eng.dims.lm.num_attention_heads, eng.dims.lm.head_dim, sub.Smax, 0)
+    hn = eng.forward_hidden(ids[b0:b0 + C], None, pc.repeat(C, 1, 1), torch.zeros(C, dtype=torch.int32, device=dev), save=False, kv_sink=sink)
+    last = hn.view(C, S0, -1)[:, -1].contiguous()
+    dec.lg[b0:b0 + C] = eng.logits(last)
+torch.cuda.synchronize()
+t_prefill = time.perf_counter() - t0
+dec.mask = torch.ones(B, S0 + T, dtype=torch.uint8, device=dev)
+dec.seq = torch.zeros(B, S0 + T, dtype=torch.int64, device=dev)
+dec.seq[:, :S0] = ids
+dec.pos = S0
+lg_prefill = dec.lg.clone()
+seq, _ = dec.greedy(T, use_graph=True, keep_scores=False)          # capture + first replay
+torch.cuda.synchronize()
+seq0 = dec.seq.clone()
+reps, ms = 3, 0.0
+for _ in range(reps):
+    dec.lg.copy_(lg_prefill)                                       # every replay restarts from the prefill logits
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    dec.graph.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    ms += e0.elapsed_time(e1) / reps
+lm = dims.lm
+p_llm = sum(p.numel() for n, p in m.named_parameters() if n.startswith(("model.layers.", "lm_head", "model.norm"))) * 2
+kv_step = [B * (S0 + t + 1) * 2 * lm.hidden_size * 2 * lm.num_hidden_layers for t in range(T - 1)]
+alg_bytes = (T - 1) * p_llm + sum(kv_step)
+out = {"metric": "decode tokens/s (bs=%d, %d steps, hipGraph, greedy)" % (B, T), "value": round(B * T / (ms * 1e-3), 1), "unit": "tokens/s",
+       "ms_per_32_steps": round(ms, 2), "ms_per_step": round(ms / max(1, T - 1), 3), "prefill_s": round(t_prefill, 2), "prompt_len": S0,
+       "roofline": {"bound": "hbm", "achieved": round(alg_bytes / (ms * 1e-3) / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
+                    "frac": round(alg_bytes / (ms * 1e-3) / 8e12, 4), "algorithmic_GB": round(alg_bytes / 1e9, 1)},
+       "deterministic_replay": bool(torch.equal(seq0, dec.seq)), "layers": lm.num_hidden_layers}
+print(json.dumps(out))
