@@ -145,6 +145,21 @@ class Engine:
 
     # ------------------------------------------------------------------------------------ PointBERT
     @torch.no_grad()
+    def pointnet(self, nb2d, BG, K):
+        """mini-PointNet (A6, dvae.py:207-221) on [BG*K, C] neighbourhood rows -> [BG, encoder_dims].
+        BatchNorm (running stats) is folded into the two convs that precede a ReLU."""
+        if not self.prepared:
+            self.prepare()
+        w, pb, T, ws, f = self.w, self.dims.pb, self.dtype, self.ws, self.folded
+        pre = "model.point_backbone."
+        h1 = ops.linear_smallk(nb2d, f["c1_w"], f["c1_b"], act=ops.ACT_RELU, out=ws.get("pn_h1", (BG * K, pb.pn_c1), T))
+        h2 = ops.mm(h1, f["c2_w"], out=ws.get("pn_h2", (BG * K, pb.pn_c2), T), bias=w[pre + "encoder.first_conv.3.bias"])
+        cat = ops.group_max(h2, BG, K, pb.pn_c2, concat=True, out=ws.get("pn_cat", (BG * K, 2 * pb.pn_c2), T))
+        h3 = ops.mm(cat, f["c3_w"], out=ws.get("pn_h3", (BG * K, pb.pn_c3), T), bias=f["c3_b"], act=ops.ACT_RELU)
+        h4 = ops.mm(h3, f["c4_w"], out=ws.get("pn_h4", (BG * K, pb.encoder_dims), T), bias=w[pre + "encoder.second_conv.3.bias"])
+        return ops.group_max(h4, BG, K, pb.encoder_dims, out=ws.get("pn_tok", (BG, pb.encoder_dims), T))
+
+    @torch.no_grad()
     def point_backbone(self, pts: torch.Tensor, fps_start) -> torch.Tensor:
         """pts [B,N,C] f32 -> [B, G+1, D] (dtype T).  Frozen/eval path (model_arch.py:33-36,121-122)."""
         if not self.prepared:
@@ -155,15 +170,8 @@ class Engine:
         G, K, D, Pn = pb.num_group, pb.group_size, pb.trans_dim, pb.point_token_len
         idx, center = ops.fps(pts, fps_start, G)                                   # A3
         _, nb = ops.knn_group(pts, center, K, out_dtype=T)                         # A4+A5  [B,G,K,C]
-        f = self.folded
         BG = B * G
-        h1 = ops.linear_smallk(nb.view(BG * K, C), f["c1_w"], f["c1_b"], act=ops.ACT_RELU,
-                               out=ws.get("pn_h1", (BG * K, pb.pn_c1), T))         # conv+BN+ReLU
-        h2 = ops.mm(h1, f["c2_w"], out=ws.get("pn_h2", (BG * K, pb.pn_c2), T), bias=w[pre + "encoder.first_conv.3.bias"])
-        cat = ops.group_max(h2, BG, K, pb.pn_c2, concat=True, out=ws.get("pn_cat", (BG * K, 2 * pb.pn_c2), T))
-        h3 = ops.mm(cat, f["c3_w"], out=ws.get("pn_h3", (BG * K, pb.pn_c3), T), bias=f["c3_b"], act=ops.ACT_RELU)
-        h4 = ops.mm(h3, f["c4_w"], out=ws.get("pn_h4", (BG * K, pb.encoder_dims), T), bias=w[pre + "encoder.second_conv.3.bias"])
-        tok = ops.group_max(h4, BG, K, pb.encoder_dims, out=ws.get("pn_tok", (BG, pb.encoder_dims), T))
+        tok = self.pointnet(nb.view(BG * K, C), BG, K)                             # A6
         # tokens + positional embedding, written straight into rows 1..G of [B, G+1, D]
         x = ws.get("pb_x", (B, Pn, D), T)
         pos = ws.get("pb_pos", (B, Pn, D), T)
