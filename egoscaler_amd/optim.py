@@ -37,6 +37,16 @@ class EgoAdamW:
     def state_dict(self):
         return {"t": self.t, "state": {n: {k: st[k] for k in ("master", "m", "v")} for n, st in self.state.items()}}
 
+    def state_dict_cpu(self):
+        return {"t": self.t, "state": {n: {k: st[k].detach().cpu() for k in ("master", "m", "v")} for n, st in self.state.items()}}
+
+    def resync_masters(self):
+        """After loading a checkpoint: the low-precision model copies follow the fp32 masters again."""
+        for st in self.state.values():
+            if st["p"].dtype != torch.float32:
+                st["p"].data.copy_(st["master"])
+        self.model.engine.after_weights_update()
+
     def load_state_dict(self, sd):
         self.t = sd["t"]
         for n, s in sd["state"].items():

@@ -159,6 +159,27 @@ int egomi_argmax_rows(const void* logits, int64_t ld, int B, int V, int64_t* ids
                       egomi_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * A14  trajectory <-> token ids for whole batches, displacement metrics (integer contracts bit-exact).
+ * replaces models/pointllm/utils/utils.py:13-21 (discretize_action / token_to_action), :47-104
+ * (str_to_float, rt2 6-DoF: split on <tsep>, first run of six <p*> tokens per segment, unmatched
+ * segments repeat the previous step), the sequence layout of models/pointllm/dataset.py:150-194 and
+ * models/utils/metrics.py:7-55 (ADE/FDE, documented [T,D] form, float64).
+ * bins: float64 [num_bins] = numpy.linspace(-1, 1, num_bins), computed by the caller (device memory).
+ *   tokenize  : traj f32 [B,Tmax,6], steps i32 [B] (NULL = Tmax) -> ids i64 [B,L] =
+ *               <ts> (p*6 <tsep>) x steps <te> <eos> pad..., mask u8 [B,L]; err[b]=1 if L is too short
+ *               (sequence truncated to whole steps).  bin = clamp(digitize(v)-1, 0, num_bins-1).
+ *   detokenize: ids i64 [B,L] (cut at the first eos) -> out f32 [B,Tmax,6] bin values, n_steps i32 [B]
+ *   metrics   : gen/gt f32 [B,Tmax,D] with lengths (NULL = Tmax) -> ade, fde float64 [B]
+ */
+int egomi_traj_tokenize(const float* traj, const int32_t* steps, int B, int Tmax, const double* bins, int num_bins, int64_t p0,
+                        int64_t ts, int64_t tsep, int64_t te, int64_t eos, int64_t pad, int L, int64_t* ids, uint8_t* mask,
+                        int32_t* err, egomi_stream_t stream);
+int egomi_traj_detokenize(const int64_t* ids, int B, int L, const double* bins, int num_bins, int64_t p0, int64_t tsep, int64_t eos,
+                          int Tmax, float* out, int32_t* n_steps, egomi_stream_t stream);
+int egomi_traj_metrics(const float* gen, const int32_t* n_gen, const float* gt, const int32_t* n_gt, int B, int Tmax, int D, double* ade,
+                       double* fde, egomi_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Row / elementwise kernels (HBM-bound).  `dtype` is the activation/parameter dtype T.
  */
 /* LayerNorm forward with optional fused pre-add: s = x (+ add); y = (s-mean)*rstd*w + b; sum_out = s

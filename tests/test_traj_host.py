@@ -1,0 +1,28 @@
+"""CPU: the product's host-side trajectory helpers (egoscaler_amd/traj.py) reproduce the golden
+vectors recorded from the reference's own functions (tests/golden/traj.npz)."""
+import json
+import os
+
+import numpy as np
+
+from egoscaler_amd import traj as T
+
+
+def test_host_helpers_match_reference_golden(golden_dir):
+    g = np.load(os.path.join(golden_dir, "traj.npz"))
+    v = g["digitize_in"]
+    for nb in (256, 16):
+        assert np.array_equal(np.array(T.discretize_action(v, nb)), g[f"digitize_{nb}"])
+    assert np.array_equal(np.array(T.token_to_action(g["t2a_in"])), g["t2a_out"])
+    assert np.array_equal(T.rt2_scaler(g["rt2_in"].copy(), [2.5, 0.1]), g["rt2_out"])
+    s = json.load(open(os.path.join(golden_dir, "traj_strings.json")))["parse_in"]
+    assert np.array_equal(T.str_to_float(s, [2.5, 0.1], "val", rt2=True), g["parse_out"])
+    assert T.str_to_float("nothing", [2.5, 0.1], "val") is None
+    for n in (50, 20, 7, 3, 2, 1):
+        assert np.array_equal(T.preprocess_traj(g[f"pre_in_{n}"], 20), g[f"pre_out_{n}"])
+        assert np.array_equal(T.smoothing_traj(g[f"pre_in_{n}"]), g[f"smooth_out_{n}"])
+    assert T.average_displacement_error(g["m_gen"], g["m_gt"]) == float(g["ade"])
+    assert T.final_displacement_error(g["m_gen"], g["m_gt"]) == float(g["fde"])
+    assert T.average_displacement_error(g["m_gen20"][None], g["m_gt"][None]) == float(g["ade_as_called"])
+    out, pm = T.preprocess_traj(g["pre_in_7"], 20, return_padding_mask=True)
+    assert pm.tolist() == [1] * 7 + [0] * 13
