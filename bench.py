@@ -101,6 +101,7 @@ def main():
     ap.add_argument("--layers", type=int, default=None, help="debug only: fewer LLaMA layers (result is then marked invalid)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gemm-events", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo only to rehearse the N>1 code path on one GPU")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -108,12 +109,16 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", 0))
     if world != a.gpus and world > 1:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    local = local % max(1, torch.cuda.device_count())        # rehearsal: several ranks may share one GPU under gloo
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
 
     from egoscaler_amd import ops, synth
     from egoscaler_amd.config import dims_7b
