@@ -1,22 +1,23 @@
 // Tuned bf16 "NT" GEMM for the LLaMA-sized projections:  C[M,N] = A[M,K] . B[N,K]^T  (+ epilogue)
 //   * both operands K-contiguous (activation x nn.Linear weight; dgrad uses pre-transposed weights,
 //     wgrad uses transposed activations, so every big product of the path has this form)
-//   * 128x128x64 tile, 256 threads (4 waves, 2x2), v_mfma_f32_16x16x32_bf16, fp32 accumulate
+//   * BM x BN x 64 tile, one wave per 64x64 sub-tile (v_mfma_f32_16x16x32_bf16, fp32 accumulate):
+//       256x128 (8 waves, 48 KB LDS, 2 blocks/CU) for large M — rocprofv3 PMC showed the 128x128 tile
+//       parked ~49 % of wave time on vmcnt/barrier with zero LDS bank conflicts, i.e. bound by the
+//       per-CU LDS-DMA fill rate (~70 GB/s/CU from L2); the wider tile moves 25 % fewer bytes per flop
+//       128x128 (4 waves, 32 KB LDS, 4 blocks/CU) otherwise
 //   * global -> LDS by LDS-DMA (global_load_lds_dwordx4): no staging VGPRs, no ds_write
 //   * LDS image linear [row][64 k] (128-B rows); bank conflicts removed by an XOR swizzle applied to
 //     the per-lane SOURCE address and to the fragment read (chunk ^= (row>>1)&7): the 16 rows of a
-//     fragment land on 16 distinct 16-B slots of the 256-B bank row (cdna_hip_programming.md rule 21)
+//     fragment land on 16 distinct 16-B slots of the 256-B bank row (cdna_hip_programming.md rule 21);
+//     measured SQ_LDS_BANK_CONFLICT = 0
 //   * operands are fed swapped (weights as the MFMA A operand) so each lane's 4 accumulators are 4
 //     consecutive output columns -> 8-B / 16-B epilogue stores
 //   * rows beyond M / N are clamped on load and masked on store; K % 64 == 0
-//   * XCD-aware block order: the 8 XCDs each walk a contiguous strip of M-tiles, N fastest, so one
-//     XCD's L2 keeps its A rows while the B panels stream (T1)
+//   * XCD-aware block order: each XCD walks a contiguous strip of tiles, grouped 8 M-tiles deep (T1)
 #include "common.h"
 
-#define FT_BM 128
-#define FT_BN 128
 #define FT_BK 64
-#define FT_THREADS 256
 
 struct FastArgs {
     const bf16_t* A; const bf16_t* B; void* C; const bf16_t* bias; const void* residual;
@@ -33,11 +34,15 @@ __device__ __forceinline__ void glds16(const bf16_t* g, bf16_t* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((gbl_void*)g, (lds_void*)lds_wave_base, 16, 0, 0);
 }
 
-template <typename TC>
-__global__ __launch_bounds__(FT_THREADS, 3) void gemm_nt_bf16_kernel(FastArgs g) {
-    __shared__ __attribute__((aligned(16))) bf16_t smem[(FT_BM + FT_BN) * FT_BK];     // 32 KB, one array
+template <typename TC, int BM, int BN, int DB>
+__global__ __launch_bounds__((BM / 64) * (BN / 64) * 64, DB ? 2 : ((BM * BN == 256 * 128) ? 4 : 3))
+void gemm_nt_bf16_kernel(FastArgs g) {
+    constexpr int WN = BN / 64, NW = (BM / 64) * WN;
+    constexpr int A_PW = BM / 8 / NW, B_PW = BN / 8 / NW;               // 1-KiB DMA pieces (8 rows x 128 B) per wave
+    constexpr int STAGE = (BM + BN) * FT_BK;
+    __shared__ __attribute__((aligned(16))) bf16_t smem[(DB ? 2 : 1) * STAGE];   // one array (cdna guide: second-__shared__ trap)
     bf16_t* sA = smem;
-    bf16_t* sB = smem + FT_BM * FT_BK;
+    bf16_t* sB = smem + BM * FT_BK;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 
@@ -48,63 +53,92 @@ __global__ __launch_bounds__(FT_THREADS, 3) void gemm_nt_bf16_kernel(FastArgs g)
         const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     }
-    // grouped order inside the strip: 8 M-tiles x consecutive N-tiles run together, so the ~64 tiles an
-    // XCD has in flight form a square block that re-uses both A rows and B panels from its L2
+    // grouped order inside the strip: 8 M-tiles x consecutive N-tiles run together, so the tiles an XCD
+    // has in flight form a block that re-uses both A rows and B panels from its L2
     const int per_group = 8 * g.tiles_n;
     const int grp = bid / per_group, first_tm = grp * 8;
     const int gsz = (g.tiles_m - first_tm) < 8 ? (g.tiles_m - first_tm) : 8;
     const int in_g = bid - grp * per_group;
     const int tm = first_tm + in_g % gsz, tn = in_g / gsz;
-    const int m0 = tm * FT_BM, n0 = tn * FT_BN;
+    const int m0 = tm * BM, n0 = tn * BN;
 
-    // ---- per-lane LDS-DMA source pointers (4 pieces of 8 rows x 128 B per operand per wave)
-    const bf16_t* srcA[4];
-    const bf16_t* srcB[4];
+    // ---- per-lane LDS-DMA source pointers
+    const bf16_t* srcA[A_PW];
+    const bf16_t* srcB[B_PW];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int r = (wave * 4 + i) * 8 + (lane >> 3);             // row inside the tile
+    for (int i = 0; i < A_PW; ++i) {
+        const int r = (wave * A_PW + i) * 8 + (lane >> 3);          // row inside the tile
         const int chunk = (lane & 7) ^ ((r >> 1) & 7);              // swizzled 16-B chunk of the row
         int ra = m0 + r; ra = ra < g.M ? ra : g.M - 1;
-        int rb = n0 + r; rb = rb < g.N ? rb : g.N - 1;
         srcA[i] = g.A + (long long)ra * g.lda + chunk * 8;
+    }
+#pragma unroll
+    for (int i = 0; i < B_PW; ++i) {
+        const int r = (wave * B_PW + i) * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ ((r >> 1) & 7);
+        int rb = n0 + r; rb = rb < g.N ? rb : g.N - 1;
         srcB[i] = g.B + (long long)rb * g.ldb + chunk * 8;
     }
 
-    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    const int wm = (wave / WN) * 64, wn = (wave % WN) * 64;
     f32x4 acc[4][4];                                                // [n-tile j][m-tile i]
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int i = 0; i < 4; ++i) acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    // fragment read offsets (bytes are 2*elements): row (lane&15), chunk (lane>>4) + 4*ks, swizzled
     int offA[4], offB[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int ra = wm + i * 16 + (lane & 15);
-        const int rb = wn + i * 16 + (lane & 15);
-        offA[i] = ra * FT_BK;
-        offB[i] = rb * FT_BK;
+        offA[i] = (wm + i * 16 + (lane & 15)) * FT_BK;
+        offB[i] = (wn + i * 16 + (lane & 15)) * FT_BK;
     }
-    const int sw_a = ((wm + (lane & 15)) >> 1) & 7;                 // (row>>1)&7 is the same for every 16-row tile of the wave
-    const int sw_b = ((wn + (lane & 15)) >> 1) & 7;
+    const int sw = ((lane & 15) >> 1) & 7;                          // (row>>1)&7: wm, wn, 16*i are multiples of 16
     const int c0 = lane >> 4;
 
     const int nt = g.K / FT_BK;
+    if (DB) {
+        // two LDS stages: the DMA of tile t+1 is in flight while tile t is multiplied (counted vmcnt + raw
+        // s_barrier, cdna_hip_programming.md "Pipelining across barriers")
+#pragma unroll
+        for (int i = 0; i < A_PW; ++i) glds16(srcA[i], sA + (wave * A_PW + i) * 8 * FT_BK);
+#pragma unroll
+        for (int i = 0; i < B_PW; ++i) glds16(srcB[i], sB + (wave * B_PW + i) * 8 * FT_BK);
+    }
     for (int t = 0; t < nt; ++t) {
         const int k0 = t * FT_BK;
+        const bf16_t* cA = sA;
+        const bf16_t* cB = sB;
+        if (DB) {
+            cA = sA + (t & 1) * STAGE;
+            cB = sB + (t & 1) * STAGE;
+            if (t + 1 < nt) {
+                bf16_t* nA = sA + ((t + 1) & 1) * STAGE;
+                bf16_t* nB = sB + ((t + 1) & 1) * STAGE;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) glds16(srcA[i] + k0, sA + (wave * 4 + i) * 8 * FT_BK);
+                for (int i = 0; i < A_PW; ++i) glds16(srcA[i] + k0 + FT_BK, nA + (wave * A_PW + i) * 8 * FT_BK);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) glds16(srcB[i] + k0, sB + (wave * 4 + i) * 8 * FT_BK);
-        __syncthreads();                                            // emits vmcnt(0): the DMA has landed
+                for (int i = 0; i < B_PW; ++i) glds16(srcB[i] + k0 + FT_BK, nB + (wave * B_PW + i) * 8 * FT_BK);
+                if (A_PW + B_PW == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_s_barrier();
+        } else {
+#pragma unroll
+            for (int i = 0; i < A_PW; ++i) glds16(srcA[i] + k0, sA + (wave * A_PW + i) * 8 * FT_BK);
+#pragma unroll
+            for (int i = 0; i < B_PW; ++i) glds16(srcB[i] + k0, sB + (wave * B_PW + i) * 8 * FT_BK);
+            __syncthreads();                                        // emits vmcnt(0): the DMA has landed
+        }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             bf16x8 fa[4], fb[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                fa[i] = *reinterpret_cast<const bf16x8*>(sA + offA[i] + (((c0 + 4 * ks) ^ sw_a) << 3));
-                fb[i] = *reinterpret_cast<const bf16x8*>(sB + offB[i] + (((c0 + 4 * ks) ^ sw_b) << 3));
+                fa[i] = *reinterpret_cast<const bf16x8*>(cA + offA[i] + (((c0 + 4 * ks) ^ sw) << 3));
+                fb[i] = *reinterpret_cast<const bf16x8*>(cB + offB[i] + (((c0 + 4 * ks) ^ sw) << 3));
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j)
@@ -112,7 +146,12 @@ __global__ __launch_bounds__(FT_THREADS, 3) void gemm_nt_bf16_kernel(FastArgs g)
                 for (int i = 0; i < 4; ++i)
                     acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[j][i], 0, 0, 0);
         }
-        __syncthreads();                                            // tile consumed before it is overwritten
+        if (DB) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                           // stage (t&1) may be refilled by the DMA of tile t+2
+        } else {
+            __syncthreads();                                        // tile consumed before it is overwritten
+        }
     }
 
     // ---- epilogue.  acc[j][i][r] = C[m][n], n = n0+wn+16j+4*(lane>>4)+r, m = m0+wm+16i+(lane&15)
@@ -185,9 +224,31 @@ static bool fast_applicable(const egomi_gemm_desc* d) {
     return true;
 }
 
+// tile choice: 2 = 256x128, 1 = 128x128.  EGOMI_GEMM_TILE=1|2 overrides (A/B experiments).
+static int tile_choice(const egomi_gemm_desc* d) {
+    static int forced = -1;
+    if (forced < 0) { const char* e = getenv("EGOMI_GEMM_TILE"); forced = e ? atoi(e) : 0; }
+    if (forced >= 1 && forced <= 3) return forced;
+    // measured (tools/gemm_bench.py, M=5536): 256x128 wins only where N is wide enough to keep every CU at
+    // 2 resident blocks to the end (N=11008: 1168 vs 1084 TFLOP/s); at N=4096 its 704 tiles quantise worse
+    // than 1408 tiles of 128x128 (952 vs 1010)
+    return (d->M >= 2048 && d->N >= 8192) ? 2 : 1;
+}
+
 extern "C" int egomi_gemm_kernel_id(const egomi_gemm_desc* d) {
     if (!d) return EGOMI_E_BADARG;
     return (!d->force_generic && fast_applicable(d)) ? 1 : 0;
+}
+
+template <int BM, int BN, int DB>
+static int launch_fast(const egomi_gemm_desc* d, FastArgs& g, hipStream_t s) {
+    g.tiles_m = (d->M + BM - 1) / BM; g.tiles_n = (d->N + BN - 1) / BN;
+    const int nwg = g.tiles_m * g.tiles_n;
+    constexpr int threads = (BM / 64) * (BN / 64) * 64;
+    if (d->c_dtype == EGOMI_BF16) EGOMI_LAUNCH((gemm_nt_bf16_kernel<bf16_t, BM, BN, DB>), dim3(nwg), dim3(threads), 0, s, g);
+    else if (d->c_dtype == EGOMI_F32) EGOMI_LAUNCH((gemm_nt_bf16_kernel<float, BM, BN, DB>), dim3(nwg), dim3(threads), 0, s, g);
+    else return EGOMI_E_UNSUPPORTED;
+    return egomi_launch_status();
 }
 
 // returns 0 on success, <0 on error, 1 when the tuned kernel does not apply
@@ -197,10 +258,7 @@ int egomi_gemm_fast_try(const egomi_gemm_desc* d, hipStream_t s) {
     g.A = (const bf16_t*)d->A; g.B = (const bf16_t*)d->B; g.C = d->C; g.bias = (const bf16_t*)d->bias; g.residual = d->residual;
     g.M = d->M; g.N = d->N; g.K = d->K; g.lda = d->lda; g.ldb = d->ldb; g.ldc = d->ldc; g.ldr = d->ldr;
     g.alpha = d->alpha; g.accumulate = d->accumulate; g.act = d->act;
-    g.tiles_m = (d->M + FT_BM - 1) / FT_BM; g.tiles_n = (d->N + FT_BN - 1) / FT_BN;
-    const int nwg = g.tiles_m * g.tiles_n;
-    if (d->c_dtype == EGOMI_BF16) EGOMI_LAUNCH(gemm_nt_bf16_kernel<bf16_t>, dim3(nwg), dim3(FT_THREADS), 0, s, g);
-    else if (d->c_dtype == EGOMI_F32) EGOMI_LAUNCH(gemm_nt_bf16_kernel<float>, dim3(nwg), dim3(FT_THREADS), 0, s, g);
-    else return EGOMI_E_UNSUPPORTED;
-    return egomi_launch_status();
+    const int tc = tile_choice(d);
+    if (tc == 3) return launch_fast<128, 128, 1>(d, g, s);          // experiment: double-buffered 128x128
+    return tc == 2 ? launch_fast<256, 128, 0>(d, g, s) : launch_fast<128, 128, 0>(d, g, s);
 }
