@@ -34,10 +34,10 @@ __device__ __forceinline__ void glds16(const bf16_t* g, bf16_t* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((gbl_void*)g, (lds_void*)lds_wave_base, 16, 0, 0);
 }
 
-template <typename TC, int BM, int BN, int DB>
-__global__ __launch_bounds__((BM / 64) * (BN / 64) * 64, DB ? 2 : ((BM * BN == 256 * 128) ? 4 : 3))
+template <typename TC, int BM, int BN, int DB, int MT = 4>
+__global__ __launch_bounds__((BM / (16 * MT)) * (BN / 64) * 64, DB ? 2 : ((BM * BN == 256 * 128) ? 4 : 3))
 void gemm_nt_bf16_kernel(FastArgs g) {
-    constexpr int WN = BN / 64, NW = (BM / 64) * WN;
+    constexpr int WN = BN / 64, NW = (BM / (16 * MT)) * WN;
     constexpr int A_PW = BM / 8 / NW, B_PW = BN / 8 / NW;               // 1-KiB DMA pieces (8 rows x 128 B) per wave
     constexpr int STAGE = (BM + BN) * FT_BK;
     __shared__ __attribute__((aligned(16))) bf16_t smem[(DB ? 2 : 1) * STAGE];   // one array (cdna guide: second-__shared__ trap)
@@ -80,19 +80,18 @@ void gemm_nt_bf16_kernel(FastArgs g) {
         srcB[i] = g.B + (long long)rb * g.ldb + chunk * 8;
     }
 
-    const int wm = (wave / WN) * 64, wn = (wave % WN) * 64;
-    f32x4 acc[4][4];                                                // [n-tile j][m-tile i]
+    const int wm = (wave / WN) * (16 * MT), wn = (wave % WN) * 64;
+    f32x4 acc[4][MT];                                               // [n-tile j][m-tile i]
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < MT; ++i) acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    int offA[4], offB[4];
+    int offA[MT], offB[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        offA[i] = (wm + i * 16 + (lane & 15)) * FT_BK;
-        offB[i] = (wn + i * 16 + (lane & 15)) * FT_BK;
-    }
+    for (int i = 0; i < MT; ++i) offA[i] = (wm + i * 16 + (lane & 15)) * FT_BK;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) offB[i] = (wn + i * 16 + (lane & 15)) * FT_BK;
     const int sw = ((lane & 15) >> 1) & 7;                          // (row>>1)&7: wm, wn, 16*i are multiples of 16
     const int c0 = lane >> 4;
 
@@ -134,16 +133,15 @@ void gemm_nt_bf16_kernel(FastArgs g) {
         }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 fa[4], fb[4];
+            bf16x8 fa[MT], fb[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                fa[i] = *reinterpret_cast<const bf16x8*>(cA + offA[i] + (((c0 + 4 * ks) ^ sw) << 3));
-                fb[i] = *reinterpret_cast<const bf16x8*>(cB + offB[i] + (((c0 + 4 * ks) ^ sw) << 3));
-            }
+            for (int i = 0; i < MT; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(cA + offA[i] + (((c0 + 4 * ks) ^ sw) << 3));
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fb[i] = *reinterpret_cast<const bf16x8*>(cB + offB[i] + (((c0 + 4 * ks) ^ sw) << 3));
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < MT; ++i)
                     acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[j][i], 0, 0, 0);
         }
         if (DB) {
@@ -168,7 +166,7 @@ void gemm_nt_bf16_kernel(FastArgs g) {
             for (int r = 0; r < 4; ++r) if (n + r < g.N) bv[r] = bf2f(g.bias[n + r]);
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < MT; ++i) {
             const int m = m0 + wm + i * 16 + (lane & 15);
             if (m >= g.M) continue;
             float v[4];
@@ -228,7 +226,7 @@ static bool fast_applicable(const egomi_gemm_desc* d) {
 static int tile_choice(const egomi_gemm_desc* d) {
     static int forced = -1;
     if (forced < 0) { const char* e = getenv("EGOMI_GEMM_TILE"); forced = e ? atoi(e) : 0; }
-    if (forced >= 1 && forced <= 3) return forced;
+    if (forced >= 1 && forced <= 4) return forced;
     // measured (tools/gemm_bench.py, M=5536): 256x128 wins only where N is wide enough to keep every CU at
     // 2 resident blocks to the end (N=11008: 1168 vs 1084 TFLOP/s); at N=4096 its 704 tiles quantise worse
     // than 1408 tiles of 128x128 (952 vs 1010)
@@ -240,13 +238,13 @@ extern "C" int egomi_gemm_kernel_id(const egomi_gemm_desc* d) {
     return (!d->force_generic && fast_applicable(d)) ? 1 : 0;
 }
 
-template <int BM, int BN, int DB>
+template <int BM, int BN, int DB, int MT = 4>
 static int launch_fast(const egomi_gemm_desc* d, FastArgs& g, hipStream_t s) {
     g.tiles_m = (d->M + BM - 1) / BM; g.tiles_n = (d->N + BN - 1) / BN;
     const int nwg = g.tiles_m * g.tiles_n;
-    constexpr int threads = (BM / 64) * (BN / 64) * 64;
-    if (d->c_dtype == EGOMI_BF16) EGOMI_LAUNCH((gemm_nt_bf16_kernel<bf16_t, BM, BN, DB>), dim3(nwg), dim3(threads), 0, s, g);
-    else if (d->c_dtype == EGOMI_F32) EGOMI_LAUNCH((gemm_nt_bf16_kernel<float, BM, BN, DB>), dim3(nwg), dim3(threads), 0, s, g);
+    constexpr int threads = (BM / (16 * MT)) * (BN / 64) * 64;
+    if (d->c_dtype == EGOMI_BF16) EGOMI_LAUNCH((gemm_nt_bf16_kernel<bf16_t, BM, BN, DB, MT>), dim3(nwg), dim3(threads), 0, s, g);
+    else if (d->c_dtype == EGOMI_F32) EGOMI_LAUNCH((gemm_nt_bf16_kernel<float, BM, BN, DB, MT>), dim3(nwg), dim3(threads), 0, s, g);
     else return EGOMI_E_UNSUPPORTED;
     return egomi_launch_status();
 }
@@ -260,5 +258,6 @@ int egomi_gemm_fast_try(const egomi_gemm_desc* d, hipStream_t s) {
     g.alpha = d->alpha; g.accumulate = d->accumulate; g.act = d->act;
     const int tc = tile_choice(d);
     if (tc == 3) return launch_fast<128, 128, 1>(d, g, s);          // experiment: double-buffered 128x128
+    if (tc == 4) return launch_fast<256, 256, 1, 8>(d, g, s);       // experiment: 256x256, 8 waves of 128x64, double-buffered (128 KB LDS)
     return tc == 2 ? launch_fast<256, 128, 0>(d, g, s) : launch_fast<128, 128, 0>(d, g, s);
 }
