@@ -1,0 +1,100 @@
+"""GPU: build_model(args) from a LOCAL HF-style directory (config.json + model.safetensors + tokenizer
+files), the way train.py:67 / evaluate.py:79 call it: point-token ids wired from the tokenizer
+(pointllm.py:277-300), trajectory tokens appended and embeddings grown without mean-init
+(builder.py:33-46), save_pretrained / from-directory round trip, checkpoint dict load."""
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from egoscaler_amd import synth
+from egoscaler_amd.config import dims_tiny
+
+pytestmark = pytest.mark.gpu
+
+
+def _make_tokenizer(path, vocab_size):
+    from tokenizers import Tokenizer, models, pre_tokenizers
+    from transformers import PreTrainedTokenizerFast
+    vocab = {"<pad>": 0, "<s>": 1, "</s>": 2}
+    for i in range(3, vocab_size):
+        vocab[f"w{i}"] = i
+    tk = Tokenizer(models.WordLevel(vocab, unk_token="<pad>"))
+    tk.pre_tokenizer = pre_tokenizers.WhitespaceSplit()
+    fast = PreTrainedTokenizerFast(tokenizer_object=tk, bos_token="<s>", eos_token="</s>", pad_token="<pad>")
+    fast.save_pretrained(path)
+
+
+def test_build_model_from_local_directory(tmp_path):
+    from egoscaler_amd.pointllm import build_model, PointLLMConfig, TrajPointLLMForCausalLM
+    num_bins = 16
+    dims = dims_tiny()
+    base_vocab = dims.tok.point_patch                       # vocabulary before any added token
+    dims.lm.vocab_size = base_vocab
+    d = str(tmp_path / "PointLLM_tiny")
+    cfg = PointLLMConfig.from_dims(dims)
+    # a "pretrained PointLLM" directory: weights for the base vocabulary + 3 point tokens (upstream PointLLM layout)
+    dims_pt = dims_tiny()
+    dims_pt.lm.vocab_size = base_vocab + 3
+    cfg.vocab_size = base_vocab + 3
+    args0 = types.SimpleNamespace(unfreeze_pc_encoder=False, unfreeze_language_model=False, num_bins=num_bins, model_name=None)
+    m0 = TrajPointLLMForCausalLM(args0, dims_pt, None, device="cuda", dtype=torch.float32)
+    m0.config = cfg
+    m0.load_state_dict(synth.synth_state_dict(dims_pt, 0))
+    m0.save_pretrained(d)
+    _make_tokenizer(d, base_vocab)
+    assert os.path.exists(os.path.join(d, "config.json")) and os.path.exists(os.path.join(d, "model.safetensors"))
+
+    args = types.SimpleNamespace(model_name=d, num_bins=num_bins, unfreeze_pc_encoder=False, unfreeze_language_model=False)
+    model, tokenizer, pbc, use_se = build_model(args)
+    assert use_se is True
+    # point tokens were appended to the tokenizer and their ids wired into the config dict and the kernels
+    assert pbc["point_patch_token"] == base_vocab and pbc["point_start_token"] == base_vocab + 1 and pbc["point_end_token"] == base_vocab + 2
+    assert {"point_cloud_dim", "backbone_output_dim", "project_output_dim", "point_token_len", "mm_use_point_start_end",
+            "projection_hidden_layer", "projection_hidden_dim", "use_max_pool", "default_point_patch_token"} <= set(pbc)
+    t = model.dims.tok
+    assert (t.point_patch, t.point_start, t.point_end) == (base_vocab, base_vocab + 1, base_vocab + 2)
+    # <ts> <tsep> <te> + num_bins <p*> tokens grow the vocabulary; old rows are preserved, new rows ~N(0, 0.02)
+    V = base_vocab + 3 + 3 + num_bins
+    assert len(tokenizer) == V and model.state_dict()["model.embed_tokens.weight"].shape[0] == V == model.state_dict()["lm_head.weight"].shape[0]
+    assert (t.ts, t.tsep, t.te, t.p0) == tuple(tokenizer.convert_tokens_to_ids(["<ts>", "<tsep>", "<te>", "<p0>"]))
+    old = synth.synth_state_dict(dims_pt, 0)["model.embed_tokens.weight"]
+    assert torch.equal(model.state_dict()["model.embed_tokens.weight"][:base_vocab + 3].cpu(), old)
+    new = model.state_dict()["model.embed_tokens.weight"][base_vocab + 3:]
+    assert 0.005 < float(new.std()) < 0.04
+    # the built model runs: tokens assembled with the tokenizer's ids
+    dims_run = model.dims
+    toks, masks, Lp = synth.synth_batch(dims_run, 2, text_len=8, num_steps=4, max_traj_token=40)
+    pts = torch.stack([synth.synth_cloud(dims_run, i) for i in range(2)])
+    model.train()
+    loss = model.loss_and_backward(toks.cuda(), masks.cuda(), pts.cuda(), Lp, tokenizer.pad_token_id, fps_start=[0, 3])
+    assert np.isfinite(float(loss))
+    # reference checkpoint dict (train.py:287-296) loads back
+    ck = {"epoch": 0, "model_state_dict": {k: v.cpu() for k, v in model.state_dict().items()}, "global_step": 1}
+    torch.save(ck, tmp_path / "latest_model.pt")
+    model2, _, _, _ = build_model(args)
+    model2.load_state_dict(torch.load(tmp_path / "latest_model.pt", map_location="cpu", weights_only=True)["model_state_dict"])
+    with torch.no_grad():
+        a = model(input_ids=toks.cuda(), attention_mask=masks.cuda(), point_clouds=pts.cuda(), fps_start=[0, 3]).logits
+        b = model2(input_ids=toks.cuda(), attention_mask=masks.cuda(), point_clouds=pts.cuda(), fps_start=[0, 3]).logits
+    assert torch.equal(a, b)
+
+
+def test_list_of_variable_size_clouds_matches_batched():
+    """pointllm.py:117-122: point_clouds may be a list of [N_i, 6] tensors."""
+    from egoscaler_amd.pointllm import TrajPointLLMForCausalLM
+    dims = dims_tiny()
+    args = types.SimpleNamespace(unfreeze_pc_encoder=False, unfreeze_language_model=False, num_bins=dims.tok.num_bins, model_name=None)
+    m = TrajPointLLMForCausalLM(args, dims, None, device="cuda", dtype=torch.float32).eval()
+    m.load_state_dict(synth.synth_state_dict(dims, 0))
+    toks, masks, Lp = synth.synth_batch(dims, 2, text_len=8, num_steps=4, max_traj_token=40)
+    pts = torch.stack([synth.synth_cloud(dims, i) for i in range(2)]).cuda()
+    with torch.no_grad():
+        a = m(input_ids=toks.cuda(), attention_mask=masks.cuda(), point_clouds=pts, fps_start=[0, 17]).logits
+        b = m(input_ids=toks.cuda(), attention_mask=masks.cuda(), point_clouds=[pts[0], pts[1]], fps_start=[0, 17]).logits
+        big = torch.cat([pts[1], pts[1][:100] + 5.0], 0)           # a larger cloud in slot 1 changes only sample 1
+        c = m(input_ids=toks.cuda(), attention_mask=masks.cuda(), point_clouds=[pts[0], big], fps_start=[0, 17]).logits
+    assert torch.equal(a, b)
+    assert torch.equal(a[0], c[0]) and not torch.equal(a[1], c[1])
