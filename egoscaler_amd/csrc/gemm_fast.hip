@@ -25,6 +25,7 @@ struct FastArgs {
     long long lda, ldb, ldc, ldr;
     float alpha; int accumulate; int act;
     int tiles_m, tiles_n;
+    int splitk; float* ws;           // splitk > 1: block (tile, blockIdx.y) multiplies its K slice and stores a raw fp32 slab
 };
 
 typedef __attribute__((address_space(3))) void lds_void;
@@ -95,16 +96,21 @@ void gemm_nt_bf16_kernel(FastArgs g) {
     const int sw = ((lane & 15) >> 1) & 7;                          // (row>>1)&7: wm, wn, 16*i are multiples of 16
     const int c0 = lane >> 4;
 
-    const int nt = g.K / FT_BK;
+    int nt = g.K / FT_BK, t_begin = 0;
+    if (g.splitk > 1) {                                             // this block's K slice (whole 64-deep steps)
+        const int per = (nt + g.splitk - 1) / g.splitk;
+        t_begin = blockIdx.y * per;
+        nt = t_begin + per < nt ? t_begin + per : nt;
+    }
     if (DB) {
         // two LDS stages: the DMA of tile t+1 is in flight while tile t is multiplied (counted vmcnt + raw
         // s_barrier, cdna_hip_programming.md "Pipelining across barriers")
 #pragma unroll
-        for (int i = 0; i < A_PW; ++i) glds16(srcA[i], sA + (wave * A_PW + i) * 8 * FT_BK);
+        for (int i = 0; i < A_PW; ++i) glds16(srcA[i] + t_begin * FT_BK, sA + (t_begin & 1) * STAGE + (wave * A_PW + i) * 8 * FT_BK);
 #pragma unroll
-        for (int i = 0; i < B_PW; ++i) glds16(srcB[i], sB + (wave * B_PW + i) * 8 * FT_BK);
+        for (int i = 0; i < B_PW; ++i) glds16(srcB[i] + t_begin * FT_BK, sB + (t_begin & 1) * STAGE + (wave * B_PW + i) * 8 * FT_BK);
     }
-    for (int t = 0; t < nt; ++t) {
+    for (int t = t_begin; t < nt; ++t) {
         const int k0 = t * FT_BK;
         const bf16_t* cA = sA;
         const bf16_t* cB = sB;
@@ -153,6 +159,22 @@ void gemm_nt_bf16_kernel(FastArgs g) {
     }
 
     // ---- epilogue.  acc[j][i][r] = C[m][n], n = n0+wn+16j+4*(lane>>4)+r, m = m0+wm+16i+(lane&15)
+    if (g.splitk > 1) {
+        float* slab = g.ws + (long long)blockIdx.y * g.M * g.N;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + wn + j * 16 + (lane >> 4) * 4;
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const int m = m0 + wm + i * 16 + (lane & 15);
+                if (m >= g.M) continue;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (n + r < g.N) slab[(long long)m * g.N + n + r] = acc[j][i][r];
+            }
+        }
+        return;
+    }
     TC* C = reinterpret_cast<TC*>(g.C);
     const TC* R = reinterpret_cast<const TC*>(g.residual);
     const bool vec_ok = (g.ldc % 4 == 0) && (!R || g.ldr % 4 == 0);
@@ -210,6 +232,22 @@ void gemm_nt_bf16_kernel(FastArgs g) {
     }
 }
 
+// split-K combine: C = act(alpha * sum_s slab[s] + bias) + residual (+C)
+template <typename TC>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(FastArgs g) {
+    const long long total = (long long)g.M * g.N;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const int m = (int)(e / g.N), n = (int)(e % g.N);
+        float v = 0.f;
+        for (int s2 = 0; s2 < g.splitk; ++s2) v += g.ws[(long long)s2 * total + e];
+        v = act_apply(v * g.alpha + (g.bias ? bf2f(g.bias[n]) : 0.f), g.act);
+        TC* cp = reinterpret_cast<TC*>(g.C) + (long long)m * g.ldc + n;
+        if (g.residual) v += Cvt<TC>::ld(reinterpret_cast<const TC*>(g.residual) + (long long)m * g.ldr + n);
+        if (g.accumulate) v += Cvt<TC>::ld(cp);
+        Cvt<TC>::st(cp, v);
+    }
+}
+
 static bool fast_applicable(const egomi_gemm_desc* d) {
     if (d->ab_dtype != EGOMI_BF16 || d->a_layout != 0 || d->b_layout != 0) return false;
     if (d->batch > 1) return false;
@@ -243,9 +281,29 @@ static int launch_fast(const egomi_gemm_desc* d, FastArgs& g, hipStream_t s) {
     g.tiles_m = (d->M + BM - 1) / BM; g.tiles_n = (d->N + BN - 1) / BN;
     const int nwg = g.tiles_m * g.tiles_n;
     constexpr int threads = (BM / (16 * MT)) * (BN / 64) * 64;
-    if (d->c_dtype == EGOMI_BF16) EGOMI_LAUNCH((gemm_nt_bf16_kernel<bf16_t, BM, BN, DB, MT>), dim3(nwg), dim3(threads), 0, s, g);
-    else if (d->c_dtype == EGOMI_F32) EGOMI_LAUNCH((gemm_nt_bf16_kernel<float, BM, BN, DB, MT>), dim3(nwg), dim3(threads), 0, s, g);
+    // skinny products (decode, M <= 512): too few tiles to fill 256 CUs and each block is DMA-latency bound,
+    // so the K range is split over blockIdx.y into fp32 slabs (caller-provided workspace) and combined
+    g.splitk = 1; g.ws = (float*)d->workspace;
+    const int nt = d->K / FT_BK;
+    if (d->workspace && d->M <= 512 && nwg < 512) {
+        // measured (tools/gemm_bench_decode.py, M=256): ~256 blocks, and no more than ~32 K-steps per slice
+        int sk = d->split_k > 0 ? d->split_k : (256 + nwg - 1) / nwg;
+        if (d->split_k <= 0 && sk >= 1 && nt / sk > 32) sk *= 2;
+        if (sk > nt) sk = nt;
+        const long long per_slab = (long long)d->M * d->N * 4;
+        if ((long long)sk * per_slab > d->workspace_bytes) sk = (int)(d->workspace_bytes / per_slab);
+        if (sk > 1) { const int per = (nt + sk - 1) / sk; sk = (nt + per - 1) / per; }     // no empty slices
+        if (sk > 1) g.splitk = sk;
+    }
+    if (d->c_dtype == EGOMI_BF16) EGOMI_LAUNCH((gemm_nt_bf16_kernel<bf16_t, BM, BN, DB, MT>), dim3(nwg, g.splitk), dim3(threads), 0, s, g);
+    else if (d->c_dtype == EGOMI_F32) EGOMI_LAUNCH((gemm_nt_bf16_kernel<float, BM, BN, DB, MT>), dim3(nwg, g.splitk), dim3(threads), 0, s, g);
     else return EGOMI_E_UNSUPPORTED;
+    if (g.splitk > 1) {
+        const long long total = (long long)d->M * d->N;
+        const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+        if (d->c_dtype == EGOMI_BF16) EGOMI_LAUNCH(splitk_reduce_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, g);
+        else EGOMI_LAUNCH(splitk_reduce_kernel<float>, dim3(grid), dim3(256), 0, s, g);
+    }
     return egomi_launch_status();
 }
 

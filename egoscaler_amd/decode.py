@@ -44,6 +44,7 @@ class Decoder:
         self.x, self.h, self.qkv, self.ao, self.x_mid, self.h2 = z(B, d), z(B, d), z(B, 3 * d), z(B, d), z(B, d), z(B, d)
         self.gu, self.act, self.x_out, self.hn, self.lg = z(B, 2 * Fd), z(B, Fd), z(B, d), z(B, d), z(B, V)
         self.tok = z(B, 1, dtype=torch.int64)
+        self.gws = torch.empty(128 << 20, dtype=torch.uint8, device=dev)      # split-K slabs of the skinny decode GEMMs
         self.seq = None
         self.mask = None
         self.pos = 0
@@ -78,18 +79,18 @@ class Decoder:
         for l in range(L):
             p = f"model.layers.{l}."
             ops.rmsnorm(x, w[p + "input_layernorm.weight"], lm.rms_norm_eps, out=self.h)
-            ops.mm(self.h, w[p + "self_attn.q_proj.weight"], out=self.qkv[:, :d])
-            ops.mm(self.h, w[p + "self_attn.k_proj.weight"], out=self.qkv[:, d:2 * d])
-            ops.mm(self.h, w[p + "self_attn.v_proj.weight"], out=self.qkv[:, 2 * d:])
+            ops.mm(self.h, w[p + "self_attn.q_proj.weight"], out=self.qkv[:, :d], workspace=self.gws)
+            ops.mm(self.h, w[p + "self_attn.k_proj.weight"], out=self.qkv[:, d:2 * d], workspace=self.gws)
+            ops.mm(self.h, w[p + "self_attn.v_proj.weight"], out=self.qkv[:, 2 * d:], workspace=self.gws)
             ops.rope_(self.qkv, eng.cos, eng.sin, B, 1, pos, 2 * H, hd, 3 * d)
             kv_append(self.qkv[:, d:2 * d], self.qkv[:, 2 * d:], 3 * d, self.kc[l], self.vc[l], B, 1, H, hd, self.Smax, pos)
             attn_decode(self.qkv, 3 * d, self.kc[l], self.vc[l], self.mask, self.ao, B, H, hd, self.Smax, pos + 1, scale)
-            ops.mm(self.ao, w[p + "self_attn.o_proj.weight"], out=self.x_mid, residual=x)
+            ops.mm(self.ao, w[p + "self_attn.o_proj.weight"], out=self.x_mid, residual=x, workspace=self.gws)
             ops.rmsnorm(self.x_mid, w[p + "post_attention_layernorm.weight"], lm.rms_norm_eps, out=self.h2)
-            ops.mm(self.h2, w[p + "mlp.gate_proj.weight"], out=self.gu[:, :Fd])
-            ops.mm(self.h2, w[p + "mlp.up_proj.weight"], out=self.gu[:, Fd:])
+            ops.mm(self.h2, w[p + "mlp.gate_proj.weight"], out=self.gu[:, :Fd], workspace=self.gws)
+            ops.mm(self.h2, w[p + "mlp.up_proj.weight"], out=self.gu[:, Fd:], workspace=self.gws)
             ops.swiglu(self.gu[:, :Fd], self.gu[:, Fd:], self.act)
-            ops.mm(self.act, w[p + "mlp.down_proj.weight"], out=x, residual=self.x_mid)     # x is not an input of this product
+            ops.mm(self.act, w[p + "mlp.down_proj.weight"], out=x, residual=self.x_mid, workspace=self.gws)     # x is not an input of this product
         ops.rmsnorm(x, w["model.norm.weight"], lm.rms_norm_eps, out=self.hn)
         ops.mm(self.hn, w["lm_head.weight"], out=self.lg)
 

@@ -104,7 +104,8 @@ class GemmDesc(ctypes.Structure):
                 ("a_layout", c_i), ("b_layout", c_i), ("ab_dtype", c_i), ("c_dtype", c_i),
                 ("batch", c_i), ("batch_inner", c_i),
                 ("sA0", c_i64), ("sA1", c_i64), ("sB0", c_i64), ("sB1", c_i64), ("sC0", c_i64), ("sC1", c_i64),
-                ("alpha", c_f), ("accumulate", c_i), ("act", c_i), ("force_generic", c_i)]
+                ("alpha", c_f), ("accumulate", c_i), ("act", c_i), ("force_generic", c_i),
+                ("workspace", c_p), ("workspace_bytes", c_i64), ("split_k", c_i)]
 
 
 ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
@@ -130,7 +131,8 @@ PROFILER = None
 
 
 def gemm_raw(A, B, C, M, N, K, lda, ldb, ldc, a_layout=0, b_layout=0, bias=None, residual=None, ldr=0,
-             act=0, alpha=1.0, accumulate=False, batch=1, batch_inner=1, strides=(0, 0, 0, 0, 0, 0), force_generic=False):
+             act=0, alpha=1.0, accumulate=False, batch=1, batch_inner=1, strides=(0, 0, 0, 0, 0, 0), force_generic=False,
+             workspace=None, split_k=0):
     """C = act(alpha*A.B + bias) + residual (+C).  A/B/C are tensors whose data_ptr() is the first
     element of the (first) operand; all strides in elements.  See include/egomi.h."""
     if A.dtype != B.dtype:
@@ -150,6 +152,8 @@ def gemm_raw(A, B, C, M, N, K, lda, ldb, ldc, a_layout=0, b_layout=0, bias=None,
     d.batch, d.batch_inner = batch, batch_inner
     d.sA0, d.sA1, d.sB0, d.sB1, d.sC0, d.sC1 = strides
     d.alpha, d.accumulate, d.act, d.force_generic = alpha, int(accumulate), act, int(force_generic)
+    if workspace is not None:
+        d.workspace, d.workspace_bytes, d.split_k = workspace.data_ptr(), workspace.numel() * workspace.element_size(), split_k
     for t in (A, B, C):
         if not t.is_cuda:
             raise _lib.EgomiError("gemm needs device tensors")

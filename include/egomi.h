@@ -111,6 +111,9 @@ typedef struct egomi_gemm_desc {
     int accumulate;
     int act;
     int force_generic;   /* 1: never take the tuned kernel (used by tests to cross-check it) */
+    /* optional split-K for skinny products (M <= 512, e.g. single-token decode): fp32 scratch of at least
+     * split_k * M * N * 4 bytes; split_k 0 = chosen by the library from the tile count.  NULL = no split. */
+    void* workspace; int64_t workspace_bytes; int split_k;
 } egomi_gemm_desc;
 int egomi_gemm(const egomi_gemm_desc* desc, egomi_stream_t stream);
 /* which kernel egomi_gemm would run for this descriptor: 1 = tuned bf16 NT kernel, 0 = generic */

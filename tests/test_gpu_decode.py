@@ -99,3 +99,21 @@ def test_padded_prompts_decode_matches_full_forward():
         lg = m(input_ids=seq[:, :Lp + 2], attention_mask=full_mask.cuda(), point_clouds=pts.cuda(), fps_start=[0, 17]).logits[:, -1].float()
     ref = o.scores[2]
     assert float((lg - ref).abs().max()) <= 5e-2 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("M,N,K,sk", [(256, 4096, 4096, 0), (256, 1024, 11008, 8), (64, 512, 512, 4), (300, 2018, 384, 3)])
+def test_split_k_gemm_matches_unsplit(M, N, K, sk):
+    """Skinny-M products with the K range split over blocks (fp32 slabs + combine) == the unsplit kernel."""
+    from egoscaler_amd import ops
+    g = torch.Generator().manual_seed(M + N)
+    a = torch.randn(M, K, generator=g).bfloat16().cuda()
+    w = (torch.randn(N, K, generator=g) * 0.05).bfloat16().cuda()
+    bias = torch.randn(N, generator=g).bfloat16().cuda()
+    res = torch.randn(M, N, generator=g).bfloat16().cuda()
+    ws = torch.empty(64 << 20, dtype=torch.uint8, device="cuda")
+    ref = ops.mm(a, w, bias=bias, residual=res, act=ops.ACT_GELU, alpha=0.5)
+    got = ops.mm(a, w, bias=bias, residual=res, act=ops.ACT_GELU, alpha=0.5, workspace=ws, split_k=sk)
+    assert float((got.float() - ref.float()).abs().max()) <= 2e-2 * float(ref.float().abs().max())
+    tiny_ws = torch.empty(1024, dtype=torch.uint8, device="cuda")          # too small for a slab: silently unsplit
+    got2 = ops.mm(a, w, bias=bias, residual=res, act=ops.ACT_GELU, alpha=0.5, workspace=tiny_ws, split_k=sk)
+    assert torch.equal(got2, ref)
