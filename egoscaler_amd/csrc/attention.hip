@@ -59,26 +59,6 @@ __device__ __forceinline__ bf16x8 pack8(const float* v) {
     return r;
 }
 
-// stage ROWS x 128 bf16 rows (row stride ld, rows clamped to [0, row_max]) into a swizzled tile
-template <int ROWS>
-__device__ __forceinline__ void stage_load(u32x4 (&regs)[ROWS * 16 / 256], const bf16_t* base, long long ld, int row0, int row_max) {
-#pragma unroll
-    for (int i = 0; i < ROWS * 16 / 256; ++i) {
-        const int idx = threadIdx.x + 256 * i;
-        int r = row0 + (idx >> 4);
-        r = r < row_max ? r : row_max;
-        regs[i] = *reinterpret_cast<const u32x4*>(base + (long long)r * ld + (idx & 15) * 8);
-    }
-}
-template <int ROWS>
-__device__ __forceinline__ void stage_store(const u32x4 (&regs)[ROWS * 16 / 256], char* tile) {
-#pragma unroll
-    for (int i = 0; i < ROWS * 16 / 256; ++i) {
-        const int idx = threadIdx.x + 256 * i;
-        *reinterpret_cast<u32x4*>(tile + sw_off(idx >> 4, idx & 15)) = regs[i];
-    }
-}
-
 // LDS-DMA one ROWS x 128 bf16 tile (rows clamped to row_max) into a swizzled LDS image: the LDS
 // destination of a wave instruction is linear (4 rows x 16 chunks), so the swizzle goes on the SOURCE.
 typedef __attribute__((address_space(3))) void lds_void_t;

@@ -10,8 +10,7 @@ Reference call stack this replaces:
   HF modeling_llama.py:367-418        LlamaModel.forward (32 decoder layers)
   pointllm/model/pointllm.py:227-228  lm_head ;  train.py:174-184  loss, backward
 """
-import math
-from typing import Dict, List, Optional
+from typing import Dict
 
 import torch
 
@@ -111,7 +110,7 @@ class Engine:
             g.zero_()
 
     # ------------------------------------------------------------------------------------ pieces
-    def _attention(self, tag, qkv, B, S, H, hd, out, causal, key_mask, scale, keep_P, past=None):
+    def _attention(self, qkv, B, S, H, hd, out, causal, key_mask, scale, keep_P):
         """qkv [B*S, 3*H*hd]; out [B*S, H*hd].  Unfused: scores (fp32) -> softmax -> P.V, all on the
         batched MFMA GEMM; no transposes, heads addressed by strides."""
         d = H * hd
@@ -196,7 +195,7 @@ class Engine:
             p = f"{pre}blocks.blocks.{i}."
             ops.layernorm(xf, w[p + "norm1.weight"], w[p + "norm1.bias"], pb.ln_eps, add=pos.view(M, D), sum_out=xs, out=h)
             ops.mm(h, w[p + "attn.qkv.weight"], out=qkv)
-            self._attention("pb", qkv, B, Pn, H, hd, ao, False, None, hd ** -0.5, False)
+            self._attention(qkv, B, Pn, H, hd, ao, False, None, hd ** -0.5, False)
             ops.mm(ao, w[p + "attn.proj.weight"], out=x1, bias=w[p + "attn.proj.bias"], residual=xs)
             ops.layernorm(x1, w[p + "norm2.weight"], w[p + "norm2.bias"], pb.ln_eps, out=h)
             ops.mm(h, w[p + "mlp.fc1.weight"], out=mid, bias=w[p + "mlp.fc1.bias"], act=ops.ACT_GELU)
@@ -297,7 +296,7 @@ class Engine:
                 lse = torch.empty(B, H, S, dtype=torch.float32, device=self.device) if save else ws.get("att_lse", (B, H, S), torch.float32)
                 ops.attn_fwd(qkv, B, S, H, hd, scale, ao, lse, causal=True, key_mask=key_mask)
             else:
-                Pm = self._attention("lm", qkv, B, S, H, hd, ao, True, key_mask, scale, save)
+                Pm = self._attention(qkv, B, S, H, hd, ao, True, key_mask, scale, save)
             ops.mm(ao, w[p + "self_attn.o_proj.weight"], out=x_mid, residual=x)
             ops.rmsnorm(x_mid, w[p + "post_attention_layernorm.weight"], lm.rms_norm_eps, rstd=rstd2, out=h2)
             ops.mm(h2, w[p + "mlp.gate_proj.weight"], out=gu[:, :Fd])
