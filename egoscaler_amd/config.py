@@ -23,6 +23,7 @@ class PointBertDims:
     npoints: int = 8192
     ln_eps: float = 1e-5
     bn_eps: float = 1e-5
+    drop_path_rate: float = 0.1   # stochastic depth of the ViT blocks, train mode only (YAML:5, point_encoder.py:133)
     # fixed by the reference's module definitions, not configurable there either:
     pos_hidden: int = 128     # pos_embed Linear(3,128) (point_encoder.py:127-131)
     mlp_ratio: int = 4        # Block(mlp_ratio=4.) (point_encoder.py:59)
@@ -92,7 +93,7 @@ def dims_tiny(vocab: int = 320, num_bins: int = 16) -> EgoDims:
     pos re-added per block, 2-layer projector, colour channels)."""
     pb = PointBertDims(trans_dim=96, depth=2, num_heads=3, group_size=16, num_group=32,
                        encoder_dims=64, point_dims=6, projection_hidden_dim=[64, 96],
-                       npoints=512)
+                       npoints=512, drop_path_rate=0.0)
     lm = LlamaDims(hidden_size=128, intermediate_size=352, num_hidden_layers=2,
                    num_attention_heads=4, vocab_size=vocab, max_position_embeddings=512)
     base = vocab - (3 + 3 + num_bins)

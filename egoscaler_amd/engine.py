@@ -51,6 +51,9 @@ class Engine:
         self.ctx = None
         self.grad_sync = None          # optional dp.GradSync: notified when a gradient buffer is final
         self.use_fused_attention = True
+        self.pb_trainer = None
+        self.pb_train_mode = False          # set by TrajPointLLMForCausalLM.train(): point backbone in train() mode
+        self.prepared_bn_stale = False
 
     def _notify(self, name):
         if self.grad_sync is not None and name in self.trainable and name in self.main_grad:
@@ -90,6 +93,9 @@ class Engine:
         """Called by the optimizer after a step: the resident W^T of TRAINABLE decoder weights must
         follow the new values (a 2-byte transpose pass per weight; frozen ones never change)."""
         if not self.prepared:
+            return
+        if self.pb_trainable:
+            self.prepared = False               # BN-folded convs of the eval path follow the new backbone weights
             return
         for nm, wt in self.wT.items():
             if nm in self.trainable:
@@ -227,9 +233,17 @@ class Engine:
             if isinstance(point_clouds, (list, tuple)):                          # pointllm.py:117-122
                 fl = [self.point_backbone(pc[None].to(self.device, torch.float32), [int(fps_start[i])]) for i, pc in enumerate(point_clouds)]
                 feats = torch.cat(fl, 0)
+            elif save and self.pb_train_mode and self.pb_trainable:
+                # --unfreeze_pc_encoder in train(): batch-statistics BatchNorm, DropPath, activations kept for backward
+                from .pointbert_train import PointBackboneTrainer
+                if self.pb_trainer is None:
+                    self.pb_trainer = PointBackboneTrainer(self)
+                feats, pb_ctx = self.pb_trainer.forward(point_clouds.to(self.device, torch.float32), fps_start, self.pb_trainer.drop_scales(B))
+                ctx["pb_ctx"] = pb_ctx
+                self.prepared_bn_stale = True
             else:
                 feats = self.point_backbone(point_clouds.to(self.device, torch.float32), fps_start)
-            fm = feats.view(B * Pn, pb.trans_dim)
+            fm = feats.reshape(B * Pn, pb.trans_dim)
             acts = [fm]
             nh = len(pb.projection_hidden_dim)
             cur = fm
@@ -319,6 +333,10 @@ class Engine:
         """lm_head (pointllm.py:227-228).  hn [M,d] -> [M,V]."""
         W = self.w["lm_head.weight"]
         return ops.mm(hn, W, out=torch.empty(hn.shape[0], W.shape[0], dtype=self.dtype, device=self.device))
+
+    @property
+    def pb_trainable(self):
+        return any(n.startswith("model.point_backbone.") for n in self.trainable)
 
     @property
     def any_layer_trainable(self):
@@ -421,6 +439,13 @@ class Engine:
                 if j > 0:
                     g_in = ops.mm(g, w[Wn], out=ws.get(f"d_pp_act{j}", (B * Pn, w[Wn].shape[1]), T), b_layout=1)
                     g = ops.gelu_bwd(g_in, acts[2 * j - 1], out=ws.get(f"d_pp_pre{j}", g_in.shape, T))
+                elif ctx.get("pb_ctx") is not None:
+                    d_backbone = ops.mm(g, w[Wn], b_layout=1)                  # gradient w.r.t. the PointBERT output
+                    self.pb_trainer.backward(d_backbone.view(B, Pn, pb.trans_dim), ctx["pb_ctx"])
+                    if self.grad_sync is not None:
+                        for nm in self.trainable:
+                            if nm.startswith("model.point_backbone."):
+                                self._notify(nm)
         if self.grad_sync is not None:
             self._notify(emb_name)
             for j in range(len(pb.projection_hidden_dim) + 1):

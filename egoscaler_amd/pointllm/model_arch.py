@@ -224,13 +224,12 @@ class TrajPointLLMForCausalLM(nn.Module):
         """model_arch.py:33-51: point backbone frozen unless --unfreeze_pc_encoder; model.layers
         frozen unless --unfreeze_language_model; embed_tokens always trainable; everything else
         (point_proj, model.norm, lm_head) keeps requires_grad=True."""
-        if getattr(self.args, "unfreeze_pc_encoder", False):
-            raise NotImplementedError("--unfreeze_pc_encoder (PointBERT backward) is not built yet")
+        unfreeze_pc = bool(getattr(self.args, "unfreeze_pc_encoder", False))
         unfreeze_llm = bool(getattr(self.args, "unfreeze_language_model", False))
         names = []
         for n, p in self.named_parameters():
             if n.startswith("model.point_backbone."):
-                p.requires_grad = False
+                p.requires_grad = unfreeze_pc
             elif n.startswith("model.layers."):
                 p.requires_grad = unfreeze_llm
             else:
@@ -412,4 +411,7 @@ class TrajPointLLMForCausalLM(nn.Module):
             self.model.embed_tokens.train(mode)
         if not getattr(self.args, "unfreeze_pc_encoder", False):
             self.model.point_backbone.eval()
+        self.engine.pb_train_mode = bool(mode) and bool(getattr(self.args, "unfreeze_pc_encoder", False))
+        if self.engine.prepared_bn_stale and not self.engine.pb_train_mode:
+            self.engine.prepared, self.engine.prepared_bn_stale = False, False      # running stats moved: re-fold BN for eval
         return self

@@ -183,6 +183,34 @@ int egomi_traj_metrics(const float* gen, const int32_t* n_gen, const float* gt, 
                        double* fde, egomi_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Trainable point backbone (--unfreeze_pc_encoder, models/pointllm/model_arch.py:33-36): the backward
+ * and train-mode pieces of pointbert/dvae.py:189-221 (Conv1d / BatchNorm1d / ReLU / max) and
+ * pointbert/point_encoder.py:58-76,142 (LayerNorm, DropPath residual).
+ *   layernorm_bwd : dx = dx_add + LN'(dy); dw, db (fp32 [cols], caller-zeroed, may be NULL) accumulate
+ *   bn_train_fwd  : y = relu?(BatchNorm1d(x)) with BATCH statistics over the R rows (biased variance),
+ *                   running stats updated with `momentum` (unbiased variance), stats = fp32 [4*C]
+ *                   scratch/saved block {sum, sumsq, mean, rstd}
+ *   bn_train_bwd  : dx, dgamma, dbeta (fp32 [C], zeroed by the call) from dy, x, y and the saved stats
+ *   group_argmax  : x [BG,M,C] -> max over M and its first arg-max;  group_max_bwd scatters dout back
+ *   smallk_wgrad  : dW[n,k] (fp32, caller-zeroed/accumulating) += sum_r dy[r,n]*x[r,k], K <= 8
+ *   group_sum     : out[bg,c] = sum_m x[(bg*M+m)*ldx + c]  (backward of the expanded group-global feature)
+ *   rowscale_add  : out[r,:] = resid[r,:] + scale[r / rows_per_sample] * branch[r,:]   (DropPath)
+ */
+int egomi_layernorm_bwd(const void* dy, const void* x, const void* w, void* dx, const void* dx_add, float* dw, float* db,
+                        int rows, int cols, float eps, int dtype, egomi_stream_t stream);
+int egomi_bn_train_fwd(const void* x, int64_t R, int C, const void* gamma, const void* beta, float eps, int relu, void* y,
+                       float* stats, void* running_mean, void* running_var, float momentum, int dtype, egomi_stream_t stream);
+int egomi_bn_train_bwd(const void* dy, const void* x, const void* y, int64_t R, int C, const float* stats, const void* gamma, int relu,
+                       float* dgamma, float* dbeta, void* dx, int dtype, egomi_stream_t stream);
+int egomi_group_argmax(const void* x, int BG, int M, int C, void* out, int32_t* idx, int dtype, egomi_stream_t stream);
+int egomi_group_max_bwd(const void* dout, const int32_t* idx, int BG, int M, int C, void* dx, int64_t ldx, int accumulate, int dtype,
+                        egomi_stream_t stream);
+int egomi_smallk_wgrad(const void* dy, const void* x, int x_dtype, int64_t R, int N, int K, float* dW, int dtype, egomi_stream_t stream);
+int egomi_group_sum(const void* x, int BG, int M, int C, int64_t ldx, void* out, int dtype, egomi_stream_t stream);
+int egomi_rowscale_add(const void* resid, const void* branch, const float* scale, int64_t rows, int cols, int rows_per_sample, void* out,
+                       int dtype, egomi_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Row / elementwise kernels (HBM-bound).  `dtype` is the activation/parameter dtype T.
  */
 /* LayerNorm forward with optional fused pre-add: s = x (+ add); y = (s-mean)*rstd*w + b; sum_out = s

@@ -183,7 +183,7 @@ def gen_traj():
 # -------------------------------------------------------------------------------------------------
 def _pb_cfg(pb: PointBertDims):
     from easydict import EasyDict
-    return EasyDict(model=dict(NAME="PointTransformer", trans_dim=pb.trans_dim, depth=pb.depth, drop_path_rate=0.1,
+    return EasyDict(model=dict(NAME="PointTransformer", trans_dim=pb.trans_dim, depth=pb.depth, drop_path_rate=getattr(pb, "drop_path_rate", 0.1),
                                cls_dim=40, num_heads=pb.num_heads, group_size=pb.group_size, num_group=pb.num_group,
                                encoder_dims=pb.encoder_dims, point_dims=3, projection_hidden_layer=len(pb.projection_hidden_dim),
                                projection_hidden_dim=list(pb.projection_hidden_dim), use_max_pool=False), npoints=pb.npoints)
@@ -368,8 +368,77 @@ def gen_tiny_model():
     RPL.cfg_from_yaml_file = orig_cfg
 
 
+def gen_tiny_pc_unfrozen():
+    """--unfreeze_pc_encoder (model_arch.py:33-36): point backbone trainable and in train() mode (BatchNorm on
+    batch statistics, running stats updated); DropPath rate 0 (stochastic depth cannot be pinned)."""
+    import pointllm.model.pointllm as RPL
+    from pointllm.model import PointLLMLlamaForCausalLM, PointLLMConfig
+    import model_arch as RMA
+    dims = dims_tiny()
+    assert dims.pb.drop_path_rate == 0.0
+    lm, pb, tok = dims.lm, dims.pb, dims.tok
+    orig_cfg = RPL.cfg_from_yaml_file
+    RPL.cfg_from_yaml_file = lambda path: _pb_cfg(pb) if os.path.basename(path) == "tiny.yaml" else orig_cfg(path)
+    cfg = PointLLMConfig(hidden_size=lm.hidden_size, intermediate_size=lm.intermediate_size,
+                         num_hidden_layers=lm.num_hidden_layers, num_attention_heads=lm.num_attention_heads,
+                         num_key_value_heads=lm.num_attention_heads, vocab_size=lm.vocab_size,
+                         rms_norm_eps=lm.rms_norm_eps, max_position_embeddings=lm.max_position_embeddings,
+                         pad_token_id=tok.pad, bos_token_id=tok.bos, eos_token_id=tok.eos,
+                         point_backbone="PointBERT", point_backbone_config_name="tiny", use_color=True,
+                         mm_use_point_start_end=True, DEFAULT_POINT_PATCH_TOKEN="<point_patch>",
+                         DEFAULT_POINT_START_TOKEN="<point_start>", DEFAULT_POINT_END_TOKEN="<point_end>",
+                         tie_word_embeddings=False, attn_implementation="eager")
+    base = PointLLMLlamaForCausalLM(cfg)
+    sd = synth.synth_state_dict(dims, 0)
+    base.load_state_dict(sd, strict=True)
+    tmp = tempfile.mkdtemp()
+    base.save_pretrained(tmp)
+    args = types.SimpleNamespace(unfreeze_pc_encoder=True, unfreeze_language_model=False, model_name=tmp, num_bins=tok.num_bins)
+    model = RMA.TrajPointLLMForCausalLM(args, cfg, tmp)
+    model.load_state_dict(sd, strict=True)
+    model.get_model().point_backbone_config.update(point_patch_token=tok.point_patch, point_start_token=tok.point_start, point_end_token=tok.point_end)
+    B = 2
+    toks, masks, Lp = synth.synth_batch(dims, B, text_len=8, num_steps=4, max_traj_token=40)
+    pts = torch.stack([synth.synth_cloud(dims, i) for i in range(B)])
+    start = np.array([0, 17])
+    model.train()
+    assert model.model.point_backbone.training and not model.model.layers.training
+    with fixed_fps_start(start):
+        o = model(input_ids=toks, attention_mask=masks, point_clouds=pts, return_dict=True)
+    lg = o.logits[:, Lp - 1:-1, :]
+    loss = F.cross_entropy(lg.reshape(-1, lg.shape[-1]), toks[:, Lp:].flatten(), ignore_index=tok.pad)
+    loss.backward()
+    grads = {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+    pbn = sorted(n for n in grads if n.startswith("model.point_backbone."))
+    assert len(pbn) > 20 and not any(n.startswith("model.layers.") for n in grads)
+    # oracle (train-mode BatchNorm) vs reference
+    sd_o = {k: v.clone().requires_grad_(v.dtype.is_floating_point and not k.startswith("model.layers.") and k.rsplit(".", 1)[-1] not in ("running_mean", "running_var"))
+            for k, v in sd.items()}
+    lo = OPL.forward(sd_o, dims, toks, masks, pts, start, pc_train=True)
+    loss_o = OL.traj_loss(lo, toks, Lp, tok.pad)
+    loss_o.backward()
+    worst = max(rel(sd_o[n].grad, g) for n, g in grads.items())
+    after = model.state_dict()
+    print("tiny_pc_unfrozen: loss", float(loss), float(loss_o), " worst grad rel", worst,
+          " running_mean rel", rel(sd_o["model.point_backbone.encoder.first_conv.1.running_mean"].detach(), after["model.point_backbone.encoder.first_conv.1.running_mean"]))
+    out = {"loss": np.array(float(loss)), "logits": o.logits.detach().numpy(), "fps_start": start, "grad_names_all": np.array(sorted(grads))}
+    keep = ["cls_token", "cls_pos", "encoder.first_conv.0.weight", "encoder.first_conv.0.bias", "encoder.first_conv.1.weight", "encoder.first_conv.1.bias",
+            "encoder.first_conv.3.weight", "encoder.second_conv.0.weight", "encoder.second_conv.1.weight", "encoder.second_conv.1.bias",
+            "encoder.second_conv.3.weight", "encoder.second_conv.3.bias", "reduce_dim.weight", "reduce_dim.bias", "pos_embed.0.weight", "pos_embed.0.bias",
+            "pos_embed.2.weight", "blocks.blocks.0.norm1.weight", "blocks.blocks.0.norm1.bias", "blocks.blocks.0.attn.qkv.weight",
+            "blocks.blocks.0.attn.proj.bias", "blocks.blocks.1.mlp.fc1.weight", "blocks.blocks.1.mlp.fc2.bias", "blocks.blocks.1.norm2.weight", "norm.weight", "norm.bias"]
+    for n in keep:
+        out["grad:model.point_backbone." + n] = grads["model.point_backbone." + n].numpy()
+    out["grad:model.point_proj.0.weight"] = grads["model.point_proj.0.weight"].numpy()
+    for n in ("encoder.first_conv.1.running_mean", "encoder.first_conv.1.running_var", "encoder.second_conv.1.running_mean",
+              "encoder.second_conv.1.running_var", "encoder.first_conv.1.num_batches_tracked"):
+        out["after:model.point_backbone." + n] = after["model.point_backbone." + n].numpy()
+    np.savez_compressed(os.path.join(GOLD, "tiny_pc_unfrozen.npz"), **out)
+    RPL.cfg_from_yaml_file = orig_cfg
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["pointcloud", "traj", "pointbert_full", "tiny_model"]
+    which = sys.argv[1:] or ["pointcloud", "traj", "pointbert_full", "tiny_model", "tiny_pc_unfrozen"]
     for w in which:
         globals()["gen_" + w]()
     sizes = {f: os.path.getsize(os.path.join(GOLD, f)) for f in sorted(os.listdir(GOLD))}

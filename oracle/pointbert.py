@@ -89,25 +89,27 @@ def group(pts: np.ndarray, num_group: int, group_size: int, start: np.ndarray):
 # ---------------------------------------------------------------------------------------------
 # A6  mini-PointNet               reference: pointbert/dvae.py:189-221
 # ---------------------------------------------------------------------------------------------
-def _bn_eval(x, sd, p, eps=1e-5):
+def _bn_eval(x, sd, p, eps=1e-5, training=False):
+    """training=True: nn.BatchNorm1d in train() mode (batch statistics, running stats updated in place with
+    momentum 0.1) — what --unfreeze_pc_encoder gives (model_arch.py:33-36,121-122)."""
     return F.batch_norm(x, sd[p + "running_mean"], sd[p + "running_var"], sd[p + "weight"], sd[p + "bias"],
-                        training=False, eps=eps)
+                        training=training, momentum=0.1, eps=eps)
 
 
-def pointnet_encoder(sd, prefix: str, neighborhood: torch.Tensor) -> torch.Tensor:
+def pointnet_encoder(sd, prefix: str, neighborhood: torch.Tensor, training=False) -> torch.Tensor:
     """[B,G,M,C] -> [B,G,encoder_dims]; BatchNorm uses running stats (frozen backbone stays in
-    eval(), model_arch.py:121-122)."""
+    eval(), model_arch.py:121-122) unless training=True."""
     B, G, M, C = neighborhood.shape
     x = neighborhood.reshape(B * G, M, C).transpose(2, 1)                        # dvae.py:213-215
     p = prefix + "first_conv."
     x = F.conv1d(x, sd[p + "0.weight"], sd[p + "0.bias"])
-    x = F.relu(_bn_eval(x, sd, p + "1."))
+    x = F.relu(_bn_eval(x, sd, p + "1.", training=training))
     x = F.conv1d(x, sd[p + "3.weight"], sd[p + "3.bias"])                        # [BG,256,M]
     g = x.max(dim=2, keepdim=True)[0]                                            # dvae.py:216
     x = torch.cat([g.expand(-1, -1, M), x], dim=1)                               # dvae.py:217
     p = prefix + "second_conv."
     x = F.conv1d(x, sd[p + "0.weight"], sd[p + "0.bias"])
-    x = F.relu(_bn_eval(x, sd, p + "1."))
+    x = F.relu(_bn_eval(x, sd, p + "1.", training=training))
     x = F.conv1d(x, sd[p + "3.weight"], sd[p + "3.bias"])
     return x.max(dim=2)[0].reshape(B, G, -1)                                     # dvae.py:219-220
 
@@ -136,9 +138,10 @@ def vit_block(sd, p, x, num_heads, eps=1e-5):
     return x + h                                                                 # point_encoder.py:75
 
 
-def point_transformer_from_groups(sd, prefix, neighborhood, center, depth, num_heads, taps=None):
-    """Everything after grouping (point_encoder.py:173-186). neighborhood/center: torch f32."""
-    tok = pointnet_encoder(sd, prefix + "encoder.", neighborhood)
+def point_transformer_from_groups(sd, prefix, neighborhood, center, depth, num_heads, taps=None, training=False):
+    """Everything after grouping (point_encoder.py:173-186). neighborhood/center: torch f32.
+    training=True: BatchNorm in train mode; DropPath is taken at rate 0 (stochastic depth is not pinned)."""
+    tok = pointnet_encoder(sd, prefix + "encoder.", neighborhood, training=training)
     if taps is not None:
         taps["pointnet"] = tok
     tok = F.linear(tok, sd[prefix + "reduce_dim.weight"], sd[prefix + "reduce_dim.bias"])
@@ -159,11 +162,11 @@ def point_transformer_from_groups(sd, prefix, neighborhood, center, depth, num_h
     return F.layer_norm(x, (C,), sd[prefix + "norm.weight"], sd[prefix + "norm.bias"], 1e-5)
 
 
-def point_transformer(sd, prefix, pts: torch.Tensor, pb, start, taps=None):
+def point_transformer(sd, prefix, pts: torch.Tensor, pb, start, taps=None, training=False):
     """pts [B,N,C] f32 -> [B,G+1,trans_dim] (use_max_pool=false: all tokens, point_encoder.py:186-187)."""
     nb, center, fidx, kidx = group(pts.detach().numpy(), pb.num_group, pb.group_size, np.asarray(start))
     if taps is not None:
         taps["fps_idx"], taps["knn_idx"] = fidx, kidx
         taps["neighborhood"], taps["center"] = nb, center
     return point_transformer_from_groups(sd, prefix, torch.from_numpy(nb), torch.from_numpy(center),
-                                         pb.depth, pb.num_heads, taps)
+                                         pb.depth, pb.num_heads, taps, training=training)

@@ -54,13 +54,18 @@ def splice(input_ids, inputs_embeds, point_features, tok, P):
     return torch.stack(rows, 0)
 
 
-def forward(sd, dims, input_ids, attention_mask, point_clouds, fps_start, kv_cache=None, taps=None):
-    """Whole model, eval-mode point backbone -> logits [B,S,V] (pointllm.py:90-178,215-228)."""
+def forward(sd, dims, input_ids, attention_mask, point_clouds, fps_start, kv_cache=None, taps=None, pc_train=False):
+    """Whole model -> logits [B,S,V] (pointllm.py:90-178,215-228).  pc_train=False: frozen eval-mode point
+    backbone (the default flags); True: --unfreeze_pc_encoder in train() (gradients flow into it, BatchNorm
+    uses batch statistics and updates the running stats held in `sd`)."""
     lm, pb, tok = dims.lm, dims.pb, dims.tok
     emb = F.embedding(input_ids, sd["model.embed_tokens.weight"])
     if point_clouds is not None and (input_ids.shape[1] != 1):
-        with torch.no_grad():
-            feats = PB.point_transformer(sd, "model.point_backbone.", point_clouds, pb, fps_start, taps)
+        if pc_train:
+            feats = PB.point_transformer(sd, "model.point_backbone.", point_clouds, pb, fps_start, taps, training=True)
+        else:
+            with torch.no_grad():
+                feats = PB.point_transformer(sd, "model.point_backbone.", point_clouds, pb, fps_start, taps)
         feats = point_proj(sd, feats, len(pb.projection_hidden_dim))
         if taps is not None:
             taps["point_features"] = feats
