@@ -168,9 +168,13 @@ void gemm_nt_bf16_kernel(FastArgs g) {
             for (int i = 0; i < MT; ++i) {
                 const int m = m0 + wm + i * 16 + (lane & 15);
                 if (m >= g.M) continue;
+                if (n + 3 < g.N && (g.N & 3) == 0) {
+                    *reinterpret_cast<f32x4*>(slab + (long long)m * g.N + n) = acc[j][i];
+                } else {
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (n + r < g.N) slab[(long long)m * g.N + n + r] = acc[j][i][r];
+                    for (int r = 0; r < 4; ++r)
+                        if (n + r < g.N) slab[(long long)m * g.N + n + r] = acc[j][i][r];
+                }
             }
         }
         return;
@@ -232,19 +236,35 @@ void gemm_nt_bf16_kernel(FastArgs g) {
     }
 }
 
-// split-K combine: C = act(alpha * sum_s slab[s] + bias) + residual (+C)
+// split-K combine: C = act(alpha * sum_s slab[s] + bias) + residual (+C); 4 columns per thread (16-B slab loads)
 template <typename TC>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(FastArgs g) {
     const long long total = (long long)g.M * g.N;
-    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
-        const int m = (int)(e / g.N), n = (int)(e % g.N);
-        float v = 0.f;
-        for (int s2 = 0; s2 < g.splitk; ++s2) v += g.ws[(long long)s2 * total + e];
-        v = act_apply(v * g.alpha + (g.bias ? bf2f(g.bias[n]) : 0.f), g.act);
-        TC* cp = reinterpret_cast<TC*>(g.C) + (long long)m * g.ldc + n;
-        if (g.residual) v += Cvt<TC>::ld(reinterpret_cast<const TC*>(g.residual) + (long long)m * g.ldr + n);
-        if (g.accumulate) v += Cvt<TC>::ld(cp);
-        Cvt<TC>::st(cp, v);
+    const int nq = (g.N + 3) >> 2;
+    const long long items = (long long)g.M * nq;
+    const bool vec = (g.N & 3) == 0;
+    for (long long it = (long long)blockIdx.x * 256 + threadIdx.x; it < items; it += (long long)gridDim.x * 256) {
+        const int m = (int)(it / nq), n = (int)(it % nq) * 4;
+        const long long e = (long long)m * g.N + n;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (vec) {
+            for (int s2 = 0; s2 < g.splitk; ++s2) {
+                const f32x4 x = *reinterpret_cast<const f32x4*>(g.ws + (long long)s2 * total + e);
+                v[0] += x[0]; v[1] += x[1]; v[2] += x[2]; v[3] += x[3];
+            }
+        } else {
+            for (int s2 = 0; s2 < g.splitk; ++s2)
+                for (int r = 0; r < 4; ++r) if (n + r < g.N) v[r] += g.ws[(long long)s2 * total + e + r];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (n + r >= g.N) continue;
+            float x = act_apply(v[r] * g.alpha + (g.bias ? bf2f(g.bias[n + r]) : 0.f), g.act);
+            TC* cp = reinterpret_cast<TC*>(g.C) + (long long)m * g.ldc + n + r;
+            if (g.residual) x += Cvt<TC>::ld(reinterpret_cast<const TC*>(g.residual) + (long long)m * g.ldr + n + r);
+            if (g.accumulate) x += Cvt<TC>::ld(cp);
+            Cvt<TC>::st(cp, x);
+        }
     }
 }
 
@@ -264,7 +284,7 @@ static bool fast_applicable(const egomi_gemm_desc* d) {
 static int tile_choice(const egomi_gemm_desc* d) {
     static int forced = -1;
     if (forced < 0) { const char* e = getenv("EGOMI_GEMM_TILE"); forced = e ? atoi(e) : 0; }
-    if (forced >= 1 && forced <= 4) return forced;
+    if (forced >= 1 && forced <= 5) return forced;
     // measured (tools/gemm_bench.py, M=5536): 256x128 wins only where N is wide enough to keep every CU at
     // 2 resident blocks to the end (N=11008: 1168 vs 1084 TFLOP/s); at N=4096 its 704 tiles quantise worse
     // than 1408 tiles of 128x128 (952 vs 1010)
@@ -287,8 +307,8 @@ static int launch_fast(const egomi_gemm_desc* d, FastArgs& g, hipStream_t s) {
     const int nt = d->K / FT_BK;
     if (d->workspace && d->M <= 512 && nwg < 512) {
         // measured (tools/gemm_bench_decode.py, M=256): ~256 blocks, and no more than ~32 K-steps per slice
-        int sk = d->split_k > 0 ? d->split_k : (256 + nwg - 1) / nwg;
-        if (d->split_k <= 0 && sk >= 1 && nt / sk > 32) sk *= 2;
+        int sk = d->split_k > 0 ? d->split_k : (nwg >= 256 ? 1 : (256 + nwg - 1) / nwg);
+        if (d->split_k <= 0 && sk > 1 && nt / sk > 32) sk *= 2;
         if (sk > nt) sk = nt;
         const long long per_slab = (long long)d->M * d->N * 4;
         if ((long long)sk * per_slab > d->workspace_bytes) sk = (int)(d->workspace_bytes / per_slab);
@@ -299,7 +319,7 @@ static int launch_fast(const egomi_gemm_desc* d, FastArgs& g, hipStream_t s) {
     else if (d->c_dtype == EGOMI_F32) EGOMI_LAUNCH((gemm_nt_bf16_kernel<float, BM, BN, DB, MT>), dim3(nwg, g.splitk), dim3(threads), 0, s, g);
     else return EGOMI_E_UNSUPPORTED;
     if (g.splitk > 1) {
-        const long long total = (long long)d->M * d->N;
+        const long long total = (long long)d->M * ((d->N + 3) / 4);
         const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
         if (d->c_dtype == EGOMI_BF16) EGOMI_LAUNCH(splitk_reduce_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, g);
         else EGOMI_LAUNCH(splitk_reduce_kernel<float>, dim3(grid), dim3(256), 0, s, g);
@@ -317,5 +337,6 @@ int egomi_gemm_fast_try(const egomi_gemm_desc* d, hipStream_t s) {
     const int tc = tile_choice(d);
     if (tc == 3) return launch_fast<128, 128, 1>(d, g, s);          // experiment: double-buffered 128x128
     if (tc == 4) return launch_fast<256, 256, 1, 8>(d, g, s);       // experiment: 256x256, 8 waves of 128x64, double-buffered (128 KB LDS)
+    if (tc == 5) return launch_fast<256, 64, 0>(d, g, s);           // skinny M (decode): all 256 rows x 64 columns per block, split-K
     return tc == 2 ? launch_fast<256, 128, 0>(d, g, s) : launch_fast<128, 128, 0>(d, g, s);
 }
