@@ -134,8 +134,16 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
 
         float s[2][16];
         float mloc = -INFINITY;
+        // causal: a 32-key sub-tile that starts beyond the wave's last query is masked for every lane -> no MFMAs
+        const int wave_qmax = q0 + wave * 32 + 31;
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
+            const bool live = !a.causal || (kv0 + 32 * sub <= wave_qmax);          // wave-uniform
+            if (!live) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[sub][r] = -INFINITY;
+                continue;
+            }
             f32x16 x;
 #pragma unroll
             for (int r = 0; r < 16; ++r) x[r] = 0.f;
@@ -173,7 +181,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
 #pragma unroll
-        for (int sub = 0; sub < 2; ++sub)
+        for (int sub = 0; sub < 2; ++sub) {
+            if (a.causal && (kv0 + 32 * sub > wave_qmax)) continue;                  // P is all zero there
 #pragma unroll
             for (int st = 0; st < 2; ++st) {
                 const bf16x8 pb = pack8(&s[sub][8 * st]);
@@ -181,6 +190,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
                 for (int dt = 0; dt < 4; ++dt)
                     o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_tr8(sV, 32 * sub + 16 * st, 32 * dt, lane), pb, o[dt], 0, 0, 0);
             }
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                                  // buffer (t&1) is free for the DMA of tile t+2
     }
@@ -277,6 +287,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(AttnArgs a) {
         const unsigned long long kmask = __ballot(sMask[kv0 + lane] != 0);
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
+            if (a.causal && (kv0 + 32 * sub > q0 + wave * 32 + 31)) continue;       // wave-uniform: every P of this sub-tile is 0
             f32x16 x, dp;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { x[r] = 0.f; dp[r] = 0.f; }

@@ -16,6 +16,10 @@
 //   * rows beyond M / N are clamped on load and masked on store; K % 64 == 0
 //   * XCD-aware block order: each XCD walks a contiguous strip of tiles, grouped 8 M-tiles deep (T1)
 #include "common.h"
+#include <mutex>
+#include <queue>
+#include <unordered_map>
+#include <vector>
 
 #define FT_BK 64
 
@@ -26,6 +30,7 @@ struct FastArgs {
     float alpha; int accumulate; int act;
     int tiles_m, tiles_n;
     int splitk; float* ws;           // splitk > 1: block (tile, blockIdx.y) multiplies its K slice and stores a raw fp32 slab
+    int full_tm, full_tiles, tail_s; // 8-phase kernel: M-tile rows >= full_tm are cut into tail_s K-slices (fp32 slabs of those rows only)
 };
 
 typedef __attribute__((address_space(3))) void lds_void;
@@ -35,8 +40,136 @@ __device__ __forceinline__ void glds16(const bf16_t* g, bf16_t* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((gbl_void*)g, (lds_void*)lds_wave_base, 16, 0, 0);
 }
 
+// ---- interior fast path of the epilogue: whole sub-tile in bounds, alpha = 1, no bias / activation, 4-aligned leading
+//      dimensions.  One pointer per lane, rows advance by a constant step, columns are immediates: a handful of
+//      instructions per 4 outputs instead of the general path's per-element checks (which cost ~20 us per 256x256 tile).
+template <typename TC, int MT, bool RES, bool ACC>
+__device__ __forceinline__ void gemm_epilogue_interior(const FastArgs& g, const f32x4 (&acc)[4][MT], const int mb, const int nb, const int lane) {
+    TC* cp = reinterpret_cast<TC*>(g.C) + (long long)(mb + (lane & 15)) * g.ldc + nb + (lane >> 4) * 4;
+    const TC* rp = RES ? reinterpret_cast<const TC*>(g.residual) + (long long)(mb + (lane & 15)) * g.ldr + nb + (lane >> 4) * 4 : nullptr;
+    const long long cstep = 16 * g.ldc, rstep = 16 * g.ldr;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            f32x4 v = acc[j][i];
+            if (sizeof(TC) == 2) {
+                if (RES) {
+                    const u32x2 rr = *reinterpret_cast<const u32x2*>(rp + j * 16);
+                    v[0] += __uint_as_float(rr[0] << 16); v[1] += __uint_as_float(rr[0] & 0xFFFF0000u);
+                    v[2] += __uint_as_float(rr[1] << 16); v[3] += __uint_as_float(rr[1] & 0xFFFF0000u);
+                }
+                if (ACC) {
+                    const u32x2 cc = *reinterpret_cast<const u32x2*>(cp + j * 16);
+                    v[0] += __uint_as_float(cc[0] << 16); v[1] += __uint_as_float(cc[0] & 0xFFFF0000u);
+                    v[2] += __uint_as_float(cc[1] << 16); v[3] += __uint_as_float(cc[1] & 0xFFFF0000u);
+                }
+                u32x2 o;
+                o[0] = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+                o[1] = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+                *reinterpret_cast<u32x2*>(cp + j * 16) = o;
+            } else {
+                if (RES) v += *reinterpret_cast<const f32x4*>(rp + j * 16);
+                if (ACC) v += *reinterpret_cast<const f32x4*>(cp + j * 16);
+                *reinterpret_cast<f32x4*>(cp + j * 16) = v;
+            }
+        }
+        cp += cstep;
+        if (RES) rp += rstep;
+    }
+}
+
+// ---- shared epilogue.  acc[j][i][r] = C[m][n], n = nb+16j+4*(lane>>4)+r, m = mb+16i+(lane&15)
+//      (nb, mb: first column / row of the wave's sub-tile)
+template <typename TC, int MT>
+__device__ __forceinline__ void gemm_epilogue(const FastArgs& g, const f32x4 (&acc)[4][MT], const int mb, const int nb, const int lane,
+                                              float* slab = nullptr, const int slab_row0 = 0) {
+    if (slab) {                                                     // raw fp32 partial sums, rows relative to slab_row0
+        slab -= (long long)slab_row0 * g.N;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = nb + j * 16 + (lane >> 4) * 4;
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const int m = mb + i * 16 + (lane & 15);
+                if (m >= g.M) continue;
+                if (n + 3 < g.N && (g.N & 3) == 0) {
+                    *reinterpret_cast<f32x4*>(slab + (long long)m * g.N + n) = acc[j][i];
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (n + r < g.N) slab[(long long)m * g.N + n + r] = acc[j][i][r];
+                }
+            }
+        }
+        return;
+    }
+    TC* C = reinterpret_cast<TC*>(g.C);
+    const TC* R = reinterpret_cast<const TC*>(g.residual);
+    const bool vec_ok = (g.ldc % 4 == 0) && (!R || g.ldr % 4 == 0);
+    if (vec_ok && !g.bias && g.act == 0 && g.alpha == 1.0f && mb + 16 * MT <= g.M && nb + 64 <= g.N) {   // wave-uniform
+        if (R) { if (g.accumulate) gemm_epilogue_interior<TC, MT, true, true>(g, acc, mb, nb, lane);
+                 else              gemm_epilogue_interior<TC, MT, true, false>(g, acc, mb, nb, lane); }
+        else   { if (g.accumulate) gemm_epilogue_interior<TC, MT, false, true>(g, acc, mb, nb, lane);
+                 else              gemm_epilogue_interior<TC, MT, false, false>(g, acc, mb, nb, lane); }
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int n = nb + j * 16 + (lane >> 4) * 4;
+        if (n >= g.N) continue;
+        float bv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (g.bias) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) if (n + r < g.N) bv[r] = bf2f(g.bias[n + r]);
+        }
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int m = mb + i * 16 + (lane & 15);
+            if (m >= g.M) continue;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = act_apply(acc[j][i][r] * g.alpha + bv[r], g.act);
+            TC* cp = C + (long long)m * g.ldc + n;
+            const TC* rp = R ? R + (long long)m * g.ldr + n : nullptr;
+            if (n + 3 < g.N && vec_ok) {
+                if (sizeof(TC) == 2) {
+                    if (rp) {
+                        const u32x2 rr = *reinterpret_cast<const u32x2*>(rp);
+                        v[0] += __uint_as_float(rr[0] << 16); v[1] += __uint_as_float(rr[0] & 0xFFFF0000u);
+                        v[2] += __uint_as_float(rr[1] << 16); v[3] += __uint_as_float(rr[1] & 0xFFFF0000u);
+                    }
+                    if (g.accumulate) {
+                        const u32x2 cc = *reinterpret_cast<const u32x2*>(cp);
+                        v[0] += __uint_as_float(cc[0] << 16); v[1] += __uint_as_float(cc[0] & 0xFFFF0000u);
+                        v[2] += __uint_as_float(cc[1] << 16); v[3] += __uint_as_float(cc[1] & 0xFFFF0000u);
+                    }
+                    u32x2 o;
+                    o[0] = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+                    o[1] = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+                    *reinterpret_cast<u32x2*>(cp) = o;
+                } else {
+                    f32x4 o = {v[0], v[1], v[2], v[3]};
+                    if (rp) o += *reinterpret_cast<const f32x4*>(rp);
+                    if (g.accumulate) o += *reinterpret_cast<const f32x4*>(cp);
+                    *reinterpret_cast<f32x4*>(cp) = o;
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (n + r >= g.N) continue;
+                    float x = v[r];
+                    if (rp) x += Cvt<TC>::ld(rp + r);
+                    if (g.accumulate) x += Cvt<TC>::ld(cp + r);
+                    Cvt<TC>::st(cp + r, x);
+                }
+            }
+        }
+    }
+}
+
 template <typename TC, int BM, int BN, int DB, int MT = 4>
-__global__ __launch_bounds__((BM / (16 * MT)) * (BN / 64) * 64, DB ? 2 : ((BM * BN == 256 * 128) ? 4 : 3))
+__global__ __launch_bounds__((BM / (16 * MT)) * (BN / 64) * 64, (DB || MT == 8) ? 2 : ((BM * BN == 256 * 128) ? 4 : 3))
 void gemm_nt_bf16_kernel(FastArgs g) {
     constexpr int WN = BN / 64, NW = (BM / (16 * MT)) * WN;
     constexpr int A_PW = BM / 8 / NW, B_PW = BN / 8 / NW;               // 1-KiB DMA pieces (8 rows x 128 B) per wave
@@ -158,83 +291,152 @@ void gemm_nt_bf16_kernel(FastArgs g) {
         }
     }
 
-    // ---- epilogue.  acc[j][i][r] = C[m][n], n = n0+wn+16j+4*(lane>>4)+r, m = m0+wm+16i+(lane&15)
-    if (g.splitk > 1) {
-        float* slab = g.ws + (long long)blockIdx.y * g.M * g.N;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int n = n0 + wn + j * 16 + (lane >> 4) * 4;
-#pragma unroll
-            for (int i = 0; i < MT; ++i) {
-                const int m = m0 + wm + i * 16 + (lane & 15);
-                if (m >= g.M) continue;
-                if (n + 3 < g.N && (g.N & 3) == 0) {
-                    *reinterpret_cast<f32x4*>(slab + (long long)m * g.N + n) = acc[j][i];
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (n + r < g.N) slab[(long long)m * g.N + n + r] = acc[j][i][r];
-                }
-            }
-        }
-        return;
-    }
-    TC* C = reinterpret_cast<TC*>(g.C);
-    const TC* R = reinterpret_cast<const TC*>(g.residual);
-    const bool vec_ok = (g.ldc % 4 == 0) && (!R || g.ldr % 4 == 0);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int n = n0 + wn + j * 16 + (lane >> 4) * 4;
-        if (n >= g.N) continue;
-        float bv[4] = {0.f, 0.f, 0.f, 0.f};
-        if (g.bias) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) if (n + r < g.N) bv[r] = bf2f(g.bias[n + r]);
-        }
-#pragma unroll
-        for (int i = 0; i < MT; ++i) {
-            const int m = m0 + wm + i * 16 + (lane & 15);
-            if (m >= g.M) continue;
-            float v[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = act_apply(acc[j][i][r] * g.alpha + bv[r], g.act);
-            TC* cp = C + (long long)m * g.ldc + n;
-            const TC* rp = R ? R + (long long)m * g.ldr + n : nullptr;
-            if (n + 3 < g.N && vec_ok) {
-                if (sizeof(TC) == 2) {
-                    if (rp) {
-                        const u32x2 rr = *reinterpret_cast<const u32x2*>(rp);
-                        v[0] += __uint_as_float(rr[0] << 16); v[1] += __uint_as_float(rr[0] & 0xFFFF0000u);
-                        v[2] += __uint_as_float(rr[1] << 16); v[3] += __uint_as_float(rr[1] & 0xFFFF0000u);
-                    }
-                    if (g.accumulate) {
-                        const u32x2 cc = *reinterpret_cast<const u32x2*>(cp);
-                        v[0] += __uint_as_float(cc[0] << 16); v[1] += __uint_as_float(cc[0] & 0xFFFF0000u);
-                        v[2] += __uint_as_float(cc[1] << 16); v[3] += __uint_as_float(cc[1] & 0xFFFF0000u);
-                    }
-                    u32x2 o;
-                    o[0] = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
-                    o[1] = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
-                    *reinterpret_cast<u32x2*>(cp) = o;
-                } else {
-                    f32x4 o = {v[0], v[1], v[2], v[3]};
-                    if (rp) o += *reinterpret_cast<const f32x4*>(rp);
-                    if (g.accumulate) o += *reinterpret_cast<const f32x4*>(cp);
-                    *reinterpret_cast<f32x4*>(cp) = o;
-                }
-            } else {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    if (n + r >= g.N) continue;
-                    float x = v[r];
-                    if (rp) x += Cvt<TC>::ld(rp + r);
-                    if (g.accumulate) x += Cvt<TC>::ld(cp + r);
-                    Cvt<TC>::st(cp + r, x);
-                }
-            }
-        }
-    }
+    gemm_epilogue<TC, MT>(g, acc, m0 + wm, n0 + wn, lane, g.splitk > 1 ? g.ws + (long long)blockIdx.y * g.M * g.N : nullptr, 0);
 }
+
+// =================================================================================================
+// 256x256 tile, 8 waves (2 M x 4 N, 128x64 per wave), 8 phases per pair of K-tiles.
+// Structure after cdna_hip_programming.md "The 256^2 8-phase template": all operand traffic is LDS-DMA
+// that stays in flight across raw s_barriers (counted vmcnt, never 0 in the loop), the two wave groups
+// (wr = 0 / 1, one wave of each per SIMD) run one barrier apart so one group's ds_read + DMA issue
+// overlaps the other's MFMA cluster.
+//   LDS  : 2 buffers x 4 half-tiles x [128 rows][64 k] bf16 = 128 KB.  Half-tiles are cut by CONSUMPTION
+//          order, not by wave: A-h{0,1} = rows {0..63, 64..127} of both wave rows, B-h{0,1} = columns
+//          {0..31, 32..63} of all four wave columns, so a half-tile is dead as soon as its phase is over.
+//   tile t (buffer b):  ph1 reads B-h0, A-h0   MFMA (A0,B0)   DMA A-h1(t+1) -> b^1
+//                       ph2 reads B-h1         MFMA (A0,B1)   DMA B-h0(t+2) -> b   (B-h0 reads retired by lgkmcnt(8) in ph1)
+//                       ph3 reads A-h1         MFMA (A1,B1)   DMA A-h0(t+2) -> b
+//                       ph4 (B0 kept in regs)  MFMA (A1,B0)   DMA B-h1(t+2) -> b ; vmcnt(6): tile t+1 has landed
+//   rows beyond M / N clamp on load, mask on store; DMAs past the last K-tile re-load the last tile into
+//   buffers nobody reads any more, which keeps the vmcnt arithmetic constant.
+// =================================================================================================
+#define P8_HT (128 * 64)
+template <typename TC>
+__global__ __launch_bounds__(512, 2)
+void gemm_nt_bf16_8phase_kernel(FastArgs g) {
+    __shared__ __attribute__((aligned(16))) bf16_t smem[2 * 4 * P8_HT];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+
+    // whole tiles first (XCD-aware strips over the first full_tm tile rows), then the K-slices of the tail rows: the
+    // dispatcher hands blocks out in index order, so the short blocks fill the ragged last round
+    int tm, tn, kz = 0, ksl = 1;
+    if ((int)blockIdx.x < g.full_tiles) {
+        const int nwg = g.full_tiles;
+        int bid = blockIdx.x;
+        const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+        const int per_group = 8 * g.tiles_n;
+        const int grp = bid / per_group, first_tm = grp * 8;
+        const int gsz = (g.full_tm - first_tm) < 8 ? (g.full_tm - first_tm) : 8;
+        const int in_g = bid - grp * per_group;
+        tm = first_tm + in_g % gsz; tn = in_g / gsz;
+    } else {
+        const int idx = blockIdx.x - g.full_tiles, rows = g.tiles_m - g.full_tm;
+        ksl = g.tail_s;
+        kz = idx % ksl;
+        const int tile = idx / ksl;
+        tm = g.full_tm + tile % rows; tn = tile / rows;
+    }
+    const int m0 = tm * 256, n0 = tn * 256;
+
+    // per-lane DMA source offsets (elements; the host checks they fit 31 bits): [half][piece]
+    unsigned offA[2][2], offB[2][2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int lr = (wave * 2 + i) * 8 + (lane >> 3);            // row of the half-tile image
+            const int chunk = (lane & 7) ^ ((lr >> 1) & 7);
+            int ra = m0 + (lr >> 6) * 128 + h * 64 + (lr & 63); ra = ra < g.M ? ra : g.M - 1;
+            int rb = n0 + (lr >> 5) * 64 + h * 32 + (lr & 31);  rb = rb < g.N ? rb : g.N - 1;
+            offA[h][i] = (unsigned)(ra * g.lda + chunk * 8);
+            offB[h][i] = (unsigned)(rb * g.ldb + chunk * 8);
+        }
+
+    f32x4 acc[4][8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // fragment read offsets (elements) inside a half-tile
+    const int sw = ((lane & 15) >> 1) & 7, c0 = lane >> 4;
+    int aBase[2], bBase[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        aBase[ks] = (wr * 64 + (lane & 15)) * 64 + (((c0 + 4 * ks) ^ sw) << 3);
+        bBase[ks] = (wc * 32 + (lane & 15)) * 64 + (((c0 + 4 * ks) ^ sw) << 3);
+    }
+
+    int nt = g.K / FT_BK, t_begin = 0;
+    if (ksl > 1) {
+        const int per = (nt + ksl - 1) / ksl;
+        t_begin = kz * per;
+        nt = t_begin + per < nt ? t_begin + per : nt;
+    }
+    const int t_last = nt - 1;
+
+    bf16x8 fa[2][4], fb0[2][2], fb1[2][2];
+
+#define P8_RD(off) (*reinterpret_cast<const bf16x8*>(smem + (off)))
+#define P8_LDA(b, X) _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int ii = 0; ii < 4; ++ii) \
+        fa[ks][ii] = P8_RD(((b) * 4 + (X)) * P8_HT + aBase[ks] + ii * 16 * 64);
+#define P8_LDB(dst, b, X) _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int jj = 0; jj < 2; ++jj) \
+        dst[ks][jj] = P8_RD(((b) * 4 + 2 + (X)) * P8_HT + bBase[ks] + jj * 16 * 64);
+#define P8_PF(b, slot, base, off) _Pragma("unroll") for (int i = 0; i < 2; ++i) \
+        glds16((base) + (off)[i], smem + ((b) * 4 + (slot)) * P8_HT + (wave * 2 + i) * 8 * 64);
+#define P8_MMA(mh, fbv, nh) __builtin_amdgcn_s_setprio(1); \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int jj = 0; jj < 2; ++jj) _Pragma("unroll") for (int ii = 0; ii < 4; ++ii) \
+            acc[(nh) * 2 + jj][(mh) * 4 + ii] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fbv[ks][jj], fa[ks][ii], acc[(nh) * 2 + jj][(mh) * 4 + ii], 0, 0, 0); \
+        __builtin_amdgcn_s_setprio(0);
+#define P8_BAR __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0);
+#define P8_TILE(b, tt) { \
+        const int t1 = (tt) + 1 < t_last ? (tt) + 1 : t_last, t2 = (tt) + 2 < t_last ? (tt) + 2 : t_last; \
+        const bf16_t* pA1 = g.A + (long long)t1 * FT_BK; \
+        const bf16_t* pA2 = g.A + (long long)t2 * FT_BK; \
+        const bf16_t* pB2 = g.B + (long long)t2 * FT_BK; \
+        /* ph1 */ P8_LDB(fb0, b, 0) __builtin_amdgcn_sched_barrier(0); P8_LDA(b, 0) P8_PF((b) ^ 1, 1, pA1, offA[1]) \
+        asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory"); P8_BAR P8_MMA(0, fb0, 0) P8_BAR \
+        /* ph2 */ P8_LDB(fb1, b, 1) P8_PF(b, 2, pB2, offB[0]) P8_BAR P8_MMA(0, fb1, 1) P8_BAR \
+        /* ph3 */ P8_LDA(b, 1) P8_PF(b, 0, pA2, offA[0]) P8_BAR P8_MMA(1, fb1, 1) P8_BAR \
+        /* ph4 */ P8_PF(b, 3, pB2, offB[1]) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); P8_BAR P8_MMA(1, fb0, 0) P8_BAR \
+    }
+
+    // ---- prologue: tile t_begin complete, three half-tiles of the next one in flight
+    {
+        const int t1 = t_begin + 1 < t_last ? t_begin + 1 : t_last;
+        const bf16_t* pA0 = g.A + (long long)t_begin * FT_BK;
+        const bf16_t* pB0 = g.B + (long long)t_begin * FT_BK;
+        const bf16_t* pA1 = g.A + (long long)t1 * FT_BK;
+        const bf16_t* pB1 = g.B + (long long)t1 * FT_BK;
+        P8_PF(0, 2, pB0, offB[0]) P8_PF(0, 0, pA0, offA[0]) P8_PF(0, 3, pB0, offB[1]) P8_PF(0, 1, pA0, offA[1])
+        P8_PF(1, 2, pB1, offB[0]) P8_PF(1, 0, pA1, offA[0]) P8_PF(1, 3, pB1, offB[1])
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        P8_BAR
+    }
+    if (wr == 1) { P8_BAR }                                       // second wave group runs one barrier behind
+    int t = t_begin;
+    for (; t + 1 < nt; t += 2) {
+        P8_TILE(0, t)
+        P8_TILE(1, t + 1)
+    }
+    if (t < nt) P8_TILE(0, t)
+    if (wr == 0) { P8_BAR }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // the tail's redundant DMAs drain before the block's LDS is released
+    const int row0 = g.full_tm * 256;
+    gemm_epilogue<TC, 8>(g, acc, m0 + wr * 128, n0 + wc * 64, lane,
+                         ksl > 1 ? g.ws + (long long)kz * (g.M - row0) * g.N : nullptr, row0);
+#undef P8_TILE
+#undef P8_BAR
+#undef P8_MMA
+#undef P8_PF
+#undef P8_LDB
+#undef P8_LDA
+#undef P8_RD
+}
+
 
 // split-K combine: C = act(alpha * sum_s slab[s] + bias) + residual (+C); 4 columns per thread (16-B slab loads)
 template <typename TC>
@@ -284,10 +486,14 @@ static bool fast_applicable(const egomi_gemm_desc* d) {
 static int tile_choice(const egomi_gemm_desc* d) {
     static int forced = -1;
     if (forced < 0) { const char* e = getenv("EGOMI_GEMM_TILE"); forced = e ? atoi(e) : 0; }
-    if (forced >= 1 && forced <= 5) return forced;
+    if (forced >= 1 && forced <= 8) return forced;
     // measured (tools/gemm_bench.py, M=5536): 256x128 wins only where N is wide enough to keep every CU at
     // 2 resident blocks to the end (N=11008: 1168 vs 1084 TFLOP/s); at N=4096 its 704 tiles quantise worse
     // than 1408 tiles of 128x128 (952 vs 1010)
+    // 256x256 8-phase kernel (tools/gemm_bench.py: 1.06-1.32 PFLOP/s at M=5536, 1.3-1.49 at M=8192 vs ~1.0-1.1): needs
+    // enough tiles to occupy the chip at one block per CU and a K long enough to amortise its prologue/epilogue
+    const long long t256 = (long long)((d->M + 255) / 256) * ((d->N + 255) / 256);
+    if (t256 >= 128 && d->K >= 2048 && (long long)d->M * d->lda < (1ll << 31) && (long long)d->N * d->ldb < (1ll << 31)) return 8;
     return (d->M >= 2048 && d->N >= 8192) ? 2 : 1;
 }
 
@@ -327,6 +533,82 @@ static int launch_fast(const egomi_gemm_desc* d, FastArgs& g, hipStream_t s) {
     return egomi_launch_status();
 }
 
+// ---- ragged last round.  One 256x256 block per CU means ceil(tiles / 256) rounds; at M = 5536, N = 4096 that is 2
+// rounds for 1.375 rounds of work.  The last `rows` tile rows are therefore cut into S K-slices (fp32 slabs of those rows
+// only, combined by splitk_reduce_kernel): short blocks that the dispatcher packs into the last round.  (rows, S) come from
+// a list-scheduling model in K-tile units, cached per shape.
+struct TailPlan { int rows, s; };
+static TailPlan plan_tail(int M, int N, int K, long long ws_bytes) {
+    static std::mutex mu;
+    static std::unordered_map<unsigned long long, TailPlan> cache;
+    const unsigned long long key = ((unsigned long long)M << 42) ^ ((unsigned long long)N << 21) ^ (unsigned long long)K ^ (ws_bytes ? 1ull << 63 : 0);
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        auto it = cache.find(key);
+        if (it != cache.end()) return it->second;
+    }
+    const int tm = (M + 255) / 256, tn = (N + 255) / 256, nt = K / FT_BK;
+    const double F = 7.0;                                             // prologue + epilogue of one block, in K-tile times (~1.4 us each)
+    auto model = [&](int rows, int S) -> double {
+        const int full = (tm - rows) * tn, Q = rows * tn * S;
+        const double cf = nt + F, cs = (nt + S - 1) / S + F + 1.0;
+        std::vector<double> t(256);
+        const int R = full / 256, r = full % 256;
+        for (int i = 0; i < 256; ++i) t[i] = (i < r ? R + 1 : R) * cf;
+        std::priority_queue<double, std::vector<double>, std::greater<double>> pq(t.begin(), t.end());
+        double end = (r ? R + 1 : R) * cf;
+        for (int q = 0; q < Q; ++q) { double x = pq.top() + cs; pq.pop(); pq.push(x); if (x > end) end = x; }
+        if (rows) end += 3.0 + (double)(M - (tm - rows) * 256) * N * 4.0 * (S + 1) / 6.3e6;     // combine pass: launch + slab traffic
+        return end;
+    };
+    TailPlan best = {0, 1};
+    double tbest = model(0, 1);
+    const double t0 = tbest;
+    for (int rows = 1; rows <= tm && rows <= 8; ++rows)
+        for (int S = 2; S <= 4; ++S) {
+            if (nt / S < 8) continue;
+            if ((long long)(M - (tm - rows) * 256) * N * 4 * S > ws_bytes) continue;
+            const double t = model(rows, S);
+            if (t < tbest) { tbest = t; best = {rows, S}; }
+        }
+    if (tbest > 0.97 * t0) best = {0, 1};                             // not worth a second launch
+    std::lock_guard<std::mutex> lk(mu);
+    cache[key] = best;
+    return best;
+}
+
+static int launch_8phase(const egomi_gemm_desc* d, FastArgs& g, hipStream_t s) {
+    g.tiles_m = (d->M + 255) / 256; g.tiles_n = (d->N + 255) / 256;
+    g.splitk = 1; g.ws = (float*)d->workspace;
+    static int no_tail = -1;
+    if (no_tail < 0) { const char* e = getenv("EGOMI_GEMM_NO_TAIL"); no_tail = e ? atoi(e) : 0; }
+    TailPlan tp = {0, 1};
+    if (d->workspace && !no_tail) tp = plan_tail(d->M, d->N, d->K, d->workspace_bytes);
+    if (d->split_k > 0 && d->workspace) {                             // explicit override (experiments): split_k = rows * 16 + S
+        tp.rows = d->split_k / 16; tp.s = d->split_k % 16;
+        if (tp.rows > g.tiles_m) tp.rows = g.tiles_m;
+        if (tp.s < 2 || tp.rows < 1) tp = {0, 1};
+    }
+    g.full_tm = g.tiles_m - tp.rows; g.tail_s = tp.s; g.full_tiles = g.full_tm * g.tiles_n;
+    const int nwg = g.full_tiles + tp.rows * g.tiles_n * tp.s;
+    if (d->c_dtype == EGOMI_BF16) EGOMI_LAUNCH(gemm_nt_bf16_8phase_kernel<bf16_t>, dim3(nwg, 1), dim3(512), 0, s, g);
+    else if (d->c_dtype == EGOMI_F32) EGOMI_LAUNCH(gemm_nt_bf16_8phase_kernel<float>, dim3(nwg, 1), dim3(512), 0, s, g);
+    else return EGOMI_E_UNSUPPORTED;
+    if (tp.rows) {
+        FastArgs r = g;
+        const long long row0 = (long long)g.full_tm * 256;
+        const int esz = d->c_dtype == EGOMI_BF16 ? 2 : 4;
+        r.M = d->M - (int)row0; r.splitk = tp.s;
+        r.C = (char*)g.C + row0 * g.ldc * esz;
+        if (g.residual) r.residual = (const char*)g.residual + row0 * g.ldr * esz;
+        const long long total = (long long)r.M * ((d->N + 3) / 4);
+        const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+        if (d->c_dtype == EGOMI_BF16) EGOMI_LAUNCH(splitk_reduce_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, r);
+        else EGOMI_LAUNCH(splitk_reduce_kernel<float>, dim3(grid), dim3(256), 0, s, r);
+    }
+    return egomi_launch_status();
+}
+
 // returns 0 on success, <0 on error, 1 when the tuned kernel does not apply
 int egomi_gemm_fast_try(const egomi_gemm_desc* d, hipStream_t s) {
     if (!fast_applicable(d)) return 1;
@@ -335,8 +617,11 @@ int egomi_gemm_fast_try(const egomi_gemm_desc* d, hipStream_t s) {
     g.M = d->M; g.N = d->N; g.K = d->K; g.lda = d->lda; g.ldb = d->ldb; g.ldc = d->ldc; g.ldr = d->ldr;
     g.alpha = d->alpha; g.accumulate = d->accumulate; g.act = d->act;
     const int tc = tile_choice(d);
+    if (tc == 8 && (long long)d->M * d->lda < (1ll << 31) && (long long)d->N * d->ldb < (1ll << 31)) return launch_8phase(d, g, s);
     if (tc == 3) return launch_fast<128, 128, 1>(d, g, s);          // experiment: double-buffered 128x128
     if (tc == 4) return launch_fast<256, 256, 1, 8>(d, g, s);       // experiment: 256x256, 8 waves of 128x64, double-buffered (128 KB LDS)
+    if (tc == 6) return launch_fast<128, 128, 0, 8>(d, g, s);       // experiment: 128x128 as 2 waves of 128x64 (LDS reads / MFMA = 0.75)
+    if (tc == 7) return launch_fast<256, 128, 0, 8>(d, g, s);       // experiment: 256x128 as 4 waves of 128x64
     if (tc == 5) return launch_fast<256, 64, 0>(d, g, s);           // skinny M (decode): all 256 rows x 64 columns per block, split-K
     return tc == 2 ? launch_fast<256, 128, 0>(d, g, s) : launch_fast<128, 128, 0>(d, g, s);
 }

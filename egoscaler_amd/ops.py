@@ -130,6 +130,17 @@ class GemmProfiler:
 PROFILER = None
 
 
+_TAIL_WS = {}
+
+
+def _tail_workspace(device, nbytes=128 << 20):
+    """One fp32 scratch buffer per device, shared by every large product (launches are stream-ordered)."""
+    ws = _TAIL_WS.get(device)
+    if ws is None:
+        ws = _TAIL_WS[device] = torch.empty(nbytes // 4, dtype=torch.float32, device=device)
+    return ws
+
+
 def gemm_raw(A, B, C, M, N, K, lda, ldb, ldc, a_layout=0, b_layout=0, bias=None, residual=None, ldr=0,
              act=0, alpha=1.0, accumulate=False, batch=1, batch_inner=1, strides=(0, 0, 0, 0, 0, 0), force_generic=False,
              workspace=None, split_k=0):
@@ -152,6 +163,8 @@ def gemm_raw(A, B, C, M, N, K, lda, ldb, ldc, a_layout=0, b_layout=0, bias=None,
     d.batch, d.batch_inner = batch, batch_inner
     d.sA0, d.sA1, d.sB0, d.sB1, d.sC0, d.sC1 = strides
     d.alpha, d.accumulate, d.act, d.force_generic = alpha, int(accumulate), act, int(force_generic)
+    if workspace is None and M >= 1024 and batch <= 1:
+        workspace = _tail_workspace(A.device)            # fp32 slabs for the ragged last round of the 256x256 kernel
     if workspace is not None:
         d.workspace, d.workspace_bytes, d.split_k = workspace.data_ptr(), workspace.numel() * workspace.element_size(), split_k
     for t in (A, B, C):
