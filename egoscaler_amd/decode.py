@@ -55,7 +55,8 @@ class Decoder:
             engine.prepare()
         self.wqkv = [engine.wqkv[l] if l in engine.wqkv else torch.cat([w[f"model.layers.{l}.self_attn.{n}_proj.weight"] for n in "qkv"], 0)
                      for l in range(L)]
-        self.wgu = [torch.cat([w[f"model.layers.{l}.mlp.{n}_proj.weight"] for n in ("gate", "up")], 0) for l in range(L)]
+        self.wgu = [engine.wgu[l] if l in engine.wgu else torch.cat([w[f"model.layers.{l}.mlp.{n}_proj.weight"] for n in ("gate", "up")], 0)
+                    for l in range(L)]
 
     # -- prefill -------------------------------------------------------------------------------------
     def _sink(self, l, qkv, B, Sq):

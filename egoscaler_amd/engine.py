@@ -92,6 +92,17 @@ class Engine:
                 p = f"model.layers.{l}.self_attn."
                 if not any((p + f"{n}_proj.weight") in self.trainable for n in "qkv"):
                     self.wqkv[l] = torch.cat([w[p + f"{n}_proj.weight"] for n in "qkv"], 0)
+        # ... and [Wgate;Wup] for the forward, [WqT|WkT|WvT] / [WgateT|WupT] (K-concatenated) for dgrad: one long-K product
+        # per block instead of 2-3 read-modify-write passes over dX; their separate W^T copies are dropped
+        self.wgu, self.wqkvT, self.wguT = {}, {}, {}
+        if self.dtype == torch.bfloat16:
+            for l in range(lm.num_hidden_layers):
+                pa, pm = f"model.layers.{l}.self_attn.", f"model.layers.{l}.mlp."
+                if l in self.wqkv:
+                    self.wqkvT[l] = torch.cat([self.wT.pop(pa + f"{n}_proj.weight") for n in "qkv"], 1)
+                if not any((pm + f"{n}_proj.weight") in self.trainable for n in ("gate", "up")):
+                    self.wgu[l] = torch.cat([w[pm + "gate_proj.weight"], w[pm + "up_proj.weight"]], 0)
+                    self.wguT[l] = torch.cat([self.wT.pop(pm + "gate_proj.weight"), self.wT.pop(pm + "up_proj.weight")], 1)
         cos, sin = ops.rope_tables(lm.max_position_embeddings, lm.head_dim, lm.rope_theta)
         self.cos, self.sin = cos.to(self.device), sin.to(self.device)
         self.prepared = True
@@ -323,8 +334,11 @@ class Engine:
                 Pm = self._attention(qkv, B, S, H, hd, ao, True, key_mask, scale, save)
             ops.mm(ao, w[p + "self_attn.o_proj.weight"], out=x_mid, residual=x)
             ops.rmsnorm(x_mid, w[p + "post_attention_layernorm.weight"], lm.rms_norm_eps, rstd=rstd2, out=h2)
-            ops.mm(h2, w[p + "mlp.gate_proj.weight"], out=gu[:, :Fd])
-            ops.mm(h2, w[p + "mlp.up_proj.weight"], out=gu[:, Fd:])
+            if l in self.wgu:
+                ops.mm(h2, self.wgu[l], out=gu)
+            else:
+                ops.mm(h2, w[p + "mlp.gate_proj.weight"], out=gu[:, :Fd])
+                ops.mm(h2, w[p + "mlp.up_proj.weight"], out=gu[:, Fd:])
             ops.swiglu(gu[:, :Fd], gu[:, Fd:], act)
             ops.mm(act, w[p + "mlp.down_proj.weight"], out=x_out, residual=x_mid)
             if save:
@@ -402,8 +416,11 @@ class Engine:
             self._wgrad(p + "mlp.down_proj.weight", dx, lc["act"])
             dgu = ws.get("dgu", (M, 2 * Fd), T)
             ops.swiglu_bwd(d_act, gu[:, :Fd], gu[:, Fd:], dgu[:, :Fd], dgu[:, Fd:])
-            d_h2 = self._dgrad(dgu[:, :Fd], p + "mlp.gate_proj.weight", ws.get("d_h", (M, d), T))
-            self._dgrad(dgu[:, Fd:], p + "mlp.up_proj.weight", d_h2, residual=d_h2)
+            if self.prepared and l in self.wguT:
+                d_h2 = ops.mm(dgu, self.wguT[l], out=ws.get("d_h", (M, d), T))
+            else:
+                d_h2 = self._dgrad(dgu[:, :Fd], p + "mlp.gate_proj.weight", ws.get("d_h", (M, d), T))
+                self._dgrad(dgu[:, Fd:], p + "mlp.up_proj.weight", d_h2, residual=d_h2)
             self._wgrad(p + "mlp.gate_proj.weight", dgu[:, :Fd], lc["h2"])
             self._wgrad(p + "mlp.up_proj.weight", dgu[:, Fd:], lc["h2"])
             n2 = p + "post_attention_layernorm.weight"
@@ -419,9 +436,12 @@ class Engine:
             else:
                 self._attention_bwd(qkv, lc["P"], d_ao, dqkv, B, S, H, hd, scale)
             ops.rope_(dqkv, self.cos, self.sin, M, S, 0, 2 * H, hd, 3 * d, inverse=True)
-            d_h = self._dgrad(dqkv[:, :d], p + "self_attn.q_proj.weight", ws.get("d_h", (M, d), T))
-            self._dgrad(dqkv[:, d:2 * d], p + "self_attn.k_proj.weight", d_h, residual=d_h)
-            self._dgrad(dqkv[:, 2 * d:], p + "self_attn.v_proj.weight", d_h, residual=d_h)
+            if self.prepared and l in self.wqkvT:
+                d_h = ops.mm(dqkv, self.wqkvT[l], out=ws.get("d_h", (M, d), T))
+            else:
+                d_h = self._dgrad(dqkv[:, :d], p + "self_attn.q_proj.weight", ws.get("d_h", (M, d), T))
+                self._dgrad(dqkv[:, d:2 * d], p + "self_attn.k_proj.weight", d_h, residual=d_h)
+                self._dgrad(dqkv[:, 2 * d:], p + "self_attn.v_proj.weight", d_h, residual=d_h)
             for i, nm in enumerate("qkv"):
                 self._wgrad(p + f"self_attn.{nm}_proj.weight", dqkv[:, i * d:(i + 1) * d], lc["h"])
             n1 = p + "input_layernorm.weight"
