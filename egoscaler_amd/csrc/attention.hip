@@ -17,6 +17,9 @@
 #include <math.h>
 
 #define AT_HD 128
+// raw v_exp_f32 (1 ulp, results below 2^-126 flush to 0): exp2f() expands to a 6-instruction denormal-safe sequence,
+// which made the softmax arithmetic the longest instruction stream of every kernel here
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
 typedef __attribute__((address_space(3))) bf16x4_t lds_bf16x4;
 
@@ -35,6 +38,17 @@ __device__ __forceinline__ int sw_off(int row, int ch) {            // byte offs
 }
 __device__ __forceinline__ int rowmap(int reg, int half) {          // C/D row of a 32x32 accumulator register
     return (reg & 3) + 8 * (reg >> 2) + 4 * half;
+}
+// Per-lane visibility bits of one 32-key sub-tile: bit c (c = rowmap(r, 0)) is set when key  key0 + 4*half + c  may be
+// attended by this lane's query (key-padding bits km32 of the sub-tile, causal limit qi).  32-bit arithmetic only.
+__device__ __forceinline__ uint32_t visible_bits(uint32_t km32, int half, int key0, int qi, int causal) {
+    uint32_t t = km32 >> (4 * half);
+    if (causal) {
+        const int lim = qi - key0 - 4 * half;                           // c <= lim
+        const uint32_t cb = lim < 0 ? 0u : (lim >= 31 ? 0xFFFFFFFFu : ((2u << lim) - 1u));
+        t &= cb;
+    }
+    return t;
 }
 __device__ __forceinline__ bf16x8 lds_row8(const char* tile, int row, int ch) {
     return *reinterpret_cast<const bf16x8*>(tile + sw_off(row, ch));
@@ -86,7 +100,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
     char* sMask = smem + 2 * 2 * 64 * 256;
     const int lane = threadIdx.x & 63, half = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 128;
+    const int b = blockIdx.z, h = blockIdx.y, q0 = (gridDim.x - 1 - blockIdx.x) * 128;   // causal: longest blocks first
     const long long row_base = (long long)b * a.S;
     const bf16_t* Q = a.q + row_base * a.ld_qkv + h * AT_HD;
     const bf16_t* K = a.k + row_base * a.ld_qkv + h * AT_HD;
@@ -150,36 +164,45 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
 #pragma unroll
             for (int ks = 0; ks < 8; ++ks)
                 x = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_row8(sK, 32 * sub + (lane & 31), 2 * ks + half), qf[ks], x, 0, 0, 0);
+            // raw scores stay in s[][] (the scale is folded into the exp); masks only where the sub-tile needs them
+            const bool interior = ((kmask >> (32 * sub)) & 0xFFFFFFFFull) == 0xFFFFFFFFull &&
+                                  (!a.causal || kv0 + 32 * sub + 31 <= q0 + wave * 32);       // wave-uniform
+            if (interior) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int kk = 32 * sub + rowmap(r, half);
-                bool ok = (kmask >> kk) & 1ull;
-                if (a.causal) ok = ok && (kv0 + kk <= qi);
-                const float v = ok ? x[r] * sc2 : -INFINITY;
-                s[sub][r] = v;
-                mloc = fmaxf(mloc, v);
+                for (int r = 0; r < 16; ++r) { s[sub][r] = x[r]; mloc = fmaxf(mloc, x[r]); }
+            } else {
+                asm volatile("");                                          // keeps the two paths apart (otherwise merged into selects)
+                const uint32_t vis = visible_bits((uint32_t)(kmask >> (32 * sub)), half, kv0 + 32 * sub, qi, a.causal);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float v = (vis >> rowmap(r, 0)) & 1u ? x[r] : -INFINITY;
+                    s[sub][r] = v;
+                    mloc = fmaxf(mloc, v);
+                }
             }
         }
-        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64)) * sc2;            // sc2 > 0: max commutes with the scale
         const float m_new = fmaxf(m_run, mloc);
         const float m_safe = m_new == -INFINITY ? 0.f : m_new;
-        const float alpha = m_run == -INFINITY ? 0.f : exp2f(m_run - m_safe);
+        const float alpha = m_run == -INFINITY ? 0.f : fast_exp2(m_run - m_safe);
         float lsum = 0.f;
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float p = exp2f(s[sub][r] - m_safe);            // exp2(-inf) = 0 for masked keys
+                const float p = fast_exp2(fmaf(s[sub][r], sc2, -m_safe));  // exp2(-inf) = 0 for masked keys
                 s[sub][r] = p;
                 lsum += p;
             }
         lsum += __shfl_xor(lsum, 32, 64);
         l_run = l_run * alpha + lsum;
         m_run = m_new;
+        if (!__all(alpha == 1.0f)) {                                   // running max unchanged for the whole wave: O keeps its scale
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt)
+            for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+                for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+        }
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
             if (a.causal && (kv0 + 32 * sub > wave_qmax)) continue;                  // P is all zero there
@@ -216,28 +239,35 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
 // backward 1/3: delta[b,h,q] = sum_d dO[q,d] * O[q,d]   (one wave per (row, head))
 // =================================================================================================
 __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* dout, const bf16_t* o, float* delta, int B, int H, int S, long long ld_o) {
-    const long long item = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    if (item >= (long long)B * S * H) return;
-    const int h = (int)(item % H);
-    const long long row = item / H;
-    const long long off = row * ld_o + h * AT_HD + lane * 2;
-    const uint32_t a = *reinterpret_cast<const uint32_t*>(dout + off), c = *reinterpret_cast<const uint32_t*>(o + off);
-    float v = __uint_as_float(a << 16) * __uint_as_float(c << 16) + __uint_as_float(a & 0xFFFF0000u) * __uint_as_float(c & 0xFFFF0000u);
-    v = wave_sum(v);
-    if (lane == 0) delta[((row / S) * H + h) * S + (row % S)] = v;
+    // 16 lanes x 8 elements (one 16-B load each of dO and O) per (row, head)
+    const long long item = (long long)blockIdx.x * 16 + (threadIdx.x >> 4);
+    const int l16 = threadIdx.x & 15;
+    const bool live = item < (long long)B * S * H;
+    const long long it = live ? item : 0;
+    const int h = (int)(it % H);
+    const long long row = it / H;
+    const long long off = row * ld_o + h * AT_HD + l16 * 8;
+    float x[8], y[8];
+    load8<bf16_t>(dout + off, x);
+    load8<bf16_t>(o + off, y);
+    float v = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v = fmaf(x[j], y[j], v);
+    v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+    if (live && l16 == 0) delta[((row / S) * H + h) * S + (row % S)] = v;
 }
 
 // =================================================================================================
 // backward 2/3: dQ.  Same structure as the forward (query on the lane): per 32-key sub-tile
 //   X = K.Q^T, dP^T = V.dO^T, dS^T = P^T*(dP^T - delta), dQ^T += K^T.dS^T
 // =================================================================================================
-__global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(AttnArgs a) {
+template <int OCC>
+__global__ __launch_bounds__(256, OCC) void attn_bwd_dq_kernel(AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* sMask = smem + 2 * 2 * 64 * 256;
+    char* sMask = smem + 3 * 2 * 64 * 256;                           // three K|V stages: two tiles stay in flight (one wave per SIMD, nothing else hides the DMA latency)
     const int lane = threadIdx.x & 63, half = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 128;
+    const int b = blockIdx.z, h = blockIdx.y, q0 = (gridDim.x - 1 - blockIdx.x) * 128;   // causal: longest blocks are dispatched first
     const long long row_base = (long long)b * a.S;
     const bf16_t* Q = a.q + row_base * a.ld_qkv + h * AT_HD;
     const bf16_t* K = a.k + row_base * a.ld_qkv + h * AT_HD;
@@ -268,23 +298,68 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(AttnArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) dq[dt][r] = 0.f;
 
-    tile_dma<64>(K, a.ld_qkv, 0, a.S - 1, smem, wave, lane);
-    tile_dma<64>(V, a.ld_qkv, 0, a.S - 1, smem + 64 * 256, wave, lane);
+    // tiles 0 and 1 in flight before the loop; past the last tile the DMA re-loads it into a stage nobody reads any more,
+    // which keeps the vmcnt arithmetic constant (8 DMAs per tile and wave)
+    {
+        const int t1 = 1 < ntiles ? 1 : ntiles - 1;
+        tile_dma<64>(K, a.ld_qkv, 0, a.S - 1, smem, wave, lane);
+        tile_dma<64>(V, a.ld_qkv, 0, a.S - 1, smem + 64 * 256, wave, lane);
+        tile_dma<64>(K, a.ld_qkv, t1 * 64, a.S - 1, smem + 2 * 64 * 256, wave, lane);
+        tile_dma<64>(V, a.ld_qkv, t1 * 64, a.S - 1, smem + 3 * 64 * 256, wave, lane);
+    }
+    int stg = 0;
     for (int t = 0; t < ntiles; ++t) {
         const int kv0 = t * 64;
-        char* sK = smem + (t & 1) * (2 * 64 * 256);
+        char* sK = smem + stg * (2 * 64 * 256);
         char* sV = sK + 64 * 256;
-        if (t + 1 < ntiles) {
-            char* nK = smem + ((t + 1) & 1) * (2 * 64 * 256);
-            tile_dma<64>(K, a.ld_qkv, kv0 + 64, a.S - 1, nK, wave, lane);
-            tile_dma<64>(V, a.ld_qkv, kv0 + 64, a.S - 1, nK + 64 * 256, wave, lane);
-            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        {
+            const int t2 = t + 2 < ntiles ? t + 2 : ntiles - 1;
+            const int s2 = stg >= 1 ? stg - 1 : 2;                     // (stg + 2) % 3
+            char* nK = smem + s2 * (2 * 64 * 256);
+            tile_dma<64>(K, a.ld_qkv, t2 * 64, a.S - 1, nK, wave, lane);
+            tile_dma<64>(V, a.ld_qkv, t2 * 64, a.S - 1, nK + 64 * 256, wave, lane);
+            asm volatile("s_waitcnt vmcnt(16)" ::: "memory");          // tile t landed; tiles t+1, t+2 stay in flight
         }
+        stg = stg == 2 ? 0 : stg + 1;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         const unsigned long long kmask = __ballot(sMask[kv0 + lane] != 0);
+        if (kmask == ~0ull && (!a.causal || kv0 + 63 <= q0 + wave * 32)) {
+            // interior tile (no mask anywhere): straight-line code, both 32-key halves in one block so the scores / dP
+            // products of the second half and the dQ products of the first run under the other half's exp/dS arithmetic
+            f32x16 x0, dp0, x1, dp1;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { x0[r] = 0.f; dp0[r] = 0.f; x1[r] = 0.f; dp1[r] = 0.f; }
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                x0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_row8(sK, lane & 31, 2 * ks + half), qf[ks], x0, 0, 0, 0);
+                dp0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_row8(sV, lane & 31, 2 * ks + half), dof[ks], dp0, 0, 0, 0);
+            }
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                x1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_row8(sK, 32 + (lane & 31), 2 * ks + half), qf[ks], x1, 0, 0, 0);
+                dp1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_row8(sV, 32 + (lane & 31), 2 * ks + half), dof[ks], dp1, 0, 0, 0);
+            }
+            float ds0[16], ds1[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ds0[r] = fast_exp2(fmaf(x0[r], sc2, -lse2)) * (dp0[r] - dlt);
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const bf16x8 db = pack8(&ds0[8 * s2]);
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt)
+                    dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_tr8(sK, 16 * s2, 32 * dt, lane), db, dq[dt], 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ds1[r] = fast_exp2(fmaf(x1[r], sc2, -lse2)) * (dp1[r] - dlt);
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const bf16x8 db = pack8(&ds1[8 * s2]);
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt)
+                    dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_tr8(sK, 32 + 16 * s2, 32 * dt, lane), db, dq[dt], 0, 0, 0);
+            }
+        } else
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
             if (a.causal && (kv0 + 32 * sub > q0 + wave * 32 + 31)) continue;       // wave-uniform: every P of this sub-tile is 0
@@ -297,13 +372,19 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(AttnArgs a) {
                 dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_row8(sV, 32 * sub + (lane & 31), 2 * ks + half), dof[ks], dp, 0, 0, 0);
             }
             float ds[16];
+            const bool interior = ((kmask >> (32 * sub)) & 0xFFFFFFFFull) == 0xFFFFFFFFull &&
+                                  (!a.causal || kv0 + 32 * sub + 31 <= q0 + wave * 32);       // wave-uniform
+            if (interior) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int kk = 32 * sub + rowmap(r, half);
-                bool ok = (kmask >> kk) & 1ull;
-                if (a.causal) ok = ok && (kv0 + kk <= qi);
-                const float p = ok ? exp2f(x[r] * sc2 - lse2) : 0.f;
-                ds[r] = p * (dp[r] - dlt);
+                for (int r = 0; r < 16; ++r) ds[r] = fast_exp2(fmaf(x[r], sc2, -lse2)) * (dp[r] - dlt);
+            } else {
+                asm volatile("");
+                const uint32_t vis = visible_bits((uint32_t)(kmask >> (32 * sub)), half, kv0 + 32 * sub, qi, a.causal);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float p = (vis >> rowmap(r, 0)) & 1u ? fast_exp2(fmaf(x[r], sc2, -lse2)) : 0.f;
+                    ds[r] = p * (dp[r] - dlt);
+                }
             }
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
@@ -316,6 +397,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(AttnArgs a) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // the tail's redundant DMAs land before the block's LDS is released
     if (qi < a.S) {
         bf16_t* orow = a.dq + (row_base + qi) * a.ld_dqkv + h * AT_HD;
 #pragma unroll
@@ -337,11 +419,12 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(AttnArgs a) {
 //   X = Q.K^T, dP = dO.V^T, P = exp2(sc2*X - lse2), dS = P*(dP - delta), dV^T += dO^T.P, dK^T += Q^T.dS
 // =================================================================================================
 #define DKV_STAGE (2 * 32 * 256 + 4 * 256)
-__global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(AttnArgs a) {
+template <int OCC>
+__global__ __launch_bounds__(256, OCC) void attn_bwd_dkdv_kernel(AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, half = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int b = blockIdx.z, h = blockIdx.y, kb0 = blockIdx.x * 128;
+    const int b = blockIdx.z, h = blockIdx.y, kb0 = blockIdx.x * 128;                   // causal: key block 0 sweeps the most queries and is dispatched first
     const long long row_base = (long long)b * a.S;
     const bf16_t* Q = a.q + row_base * a.ld_qkv + h * AT_HD;
     const bf16_t* K = a.k + row_base * a.ld_qkv + h * AT_HD;
@@ -353,6 +436,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(AttnArgs a) {
     const int kr = kj < a.S ? kj : a.S - 1;
     bool key_ok = kj < a.S;
     if (key_ok && a.key_mask) key_ok = a.key_mask[row_base + kj] != 0;
+    const bool keys_all_ok = __all(key_ok);
     bf16x8 kf[8], vf[8];
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) {
@@ -377,16 +461,19 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(AttnArgs a) {
         const float* src = (wave & 1) ? (DEL + qq) : (LSE + qq);
         __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(stage + 2 * 32 * 256 + wave * 256), 4, 0, 0);
     };
-    if (qt0 < nq) issue(qt0, smem);
+    // three stages, two query tiles in flight (one wave per SIMD: nothing else hides the DMA latency); past the last tile
+    // the DMA re-loads it into a stage nobody reads any more, which keeps the vmcnt arithmetic constant (5 DMAs per tile)
+    if (qt0 < nq) {
+        issue(qt0, smem);
+        issue(qt0 + 1 < nq ? qt0 + 1 : nq - 1, smem + DKV_STAGE);
+    }
+    int stg = 0;
     for (int qt = qt0; qt < nq; ++qt) {
         const int q0 = qt * 32;
-        char* st = smem + ((qt - qt0) & 1) * DKV_STAGE;
-        if (qt + 1 < nq) {
-            issue(qt + 1, smem + ((qt + 1 - qt0) & 1) * DKV_STAGE);
-            asm volatile("s_waitcnt vmcnt(5)" ::: "memory");           // 2 + 2 + 1 DMAs of the next tile stay in flight
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
+        char* st = smem + stg * DKV_STAGE;
+        issue(qt + 2 < nq ? qt + 2 : nq - 1, smem + (stg >= 1 ? stg - 1 : 2) * DKV_STAGE);
+        asm volatile("s_waitcnt vmcnt(10)" ::: "memory");              // tile qt landed; 2 x (2 + 2 + 1) DMAs stay in flight
+        stg = stg == 2 ? 0 : stg + 1;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         const char* sQ = st;
@@ -402,20 +489,30 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(AttnArgs a) {
             dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_row8(sDO, lane & 31, 2 * ks + half), vf[ks], dp, 0, 0, 0);
         }
         float pv[16], ds[16];
+        // masks only on edge tiles: every key of the wave visible, every query of the tile in range and (causal) not before any key
+        const bool interior = keys_all_ok && q0 + 31 < a.S && (!a.causal || kb0 + wave * 32 + 31 <= q0);      // wave-uniform
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const f32x4 l4 = *reinterpret_cast<const f32x4*>(sL + 8 * g + 4 * half);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) pv[4 * g + e] = fast_exp2(fmaf(x[4 * g + e], sc2, -l4[e] * 1.4426950408889634f));
+        }
+        if (!interior) {
+            asm volatile("");                                              // keeps the edge path a real branch
+            // query bit c = rowmap(r, 0): visible when q0 + 4*half + c is a real query and (causal) not before this lane's key
+            const int lo = a.causal ? kj - q0 - 4 * half : 0;                   // c >= lo
+            const int hi = a.S - 1 - q0 - 4 * half;                             // c <= hi
+            uint32_t vis = key_ok ? 0xFFFFFFFFu : 0u;
+            vis &= lo <= 0 ? 0xFFFFFFFFu : (lo >= 32 ? 0u : ~((1u << lo) - 1u));
+            vis &= hi < 0 ? 0u : (hi >= 31 ? 0xFFFFFFFFu : ((2u << hi) - 1u));
+#pragma unroll
+            for (int r = 0; r < 16; ++r) pv[r] = (vis >> rowmap(r, 0)) & 1u ? pv[r] : 0.f;
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
             const f32x4 d4 = *reinterpret_cast<const f32x4*>(sD + 8 * g + 4 * half);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int r = 4 * g + e;
-                const int qq = q0 + 8 * g + 4 * half + e;
-                bool ok = key_ok && qq < a.S;
-                if (a.causal) ok = ok && (kj <= qq);
-                const float p = ok ? exp2f(x[r] * sc2 - l4[e] * 1.4426950408889634f) : 0.f;
-                pv[r] = p;
-                ds[r] = p * (dp[r] - d4[e]);
-            }
+            for (int e = 0; e < 4; ++e) ds[4 * g + e] = pv[4 * g + e] * (dp[4 * g + e] - d4[e]);
         }
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
@@ -430,6 +527,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(AttnArgs a) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (kj < a.S) {
         bf16_t* krow = a.dk + (row_base + kj) * a.ld_dqkv + h * AT_HD;
         bf16_t* vrow = a.dv + (row_base + kj) * a.ld_dqkv + h * AT_HD;
@@ -483,16 +581,25 @@ extern "C" int egomi_attn_bwd(const egomi_attn_desc* d, egomi_stream_t stream) {
     if (rc) return rc;
     if (!d->o || !d->lse || !d->dout || !d->delta || !d->dq || !d->dk || !d->dv) return EGOMI_E_BADARG;
     if (d->ld_o % 8 || d->ld_dqkv % 4 || d->ld_o < AT_HD * d->H || d->ld_dqkv < AT_HD * d->H) return EGOMI_E_SHAPE;
-    if (((uintptr_t)d->dout & 15) || (((uintptr_t)d->dq | (uintptr_t)d->dk | (uintptr_t)d->dv) & 7) || ((uintptr_t)d->o & 3)) return EGOMI_E_SHAPE;
+    if (((uintptr_t)d->dout & 15) || (((uintptr_t)d->dq | (uintptr_t)d->dk | (uintptr_t)d->dv) & 7) || ((uintptr_t)d->o & 15)) return EGOMI_E_SHAPE;
     if (d->S > AT_MAXS) return EGOMI_E_UNSUPPORTED;
     AttnArgs a = attn_args(d);
     hipStream_t s = (hipStream_t)stream;
     const long long items = (long long)d->B * d->S * d->H;
-    EGOMI_LAUNCH(attn_delta_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, s, a.dout, (const bf16_t*)d->o, d->delta, d->B, d->H, d->S, d->ld_o);
-    const size_t lds_q = 2 * 2 * 64 * 256 + (size_t)((d->S + 63) / 64) * 64;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q);
-    EGOMI_LAUNCH(attn_bwd_dq_kernel, dim3((d->S + 127) / 128, d->H, d->B), dim3(256), lds_q, s, a);
-    const size_t lds_k = 2 * DKV_STAGE;
-    EGOMI_LAUNCH(attn_bwd_dkdv_kernel, dim3((d->S + 127) / 128, d->H, d->B), dim3(256), lds_k, s, a);
+    EGOMI_LAUNCH(attn_delta_kernel, dim3((unsigned)((items + 15) / 16)), dim3(256), 0, s, a.dout, (const bf16_t*)d->o, d->delta, d->B, d->H, d->S, d->ld_o);
+    const size_t lds_q = 3 * 2 * 64 * 256 + (size_t)((d->S + 63) / 64) * 64;
+    static int occ = -1;                                               // A/B switch: bit 0 / bit 1 = two waves per SIMD for dQ / dKdV
+    if (occ < 0) { const char* e = getenv("EGOMI_ATTN_OCC"); occ = e ? atoi(e) : 0; }
+    const dim3 grid((d->S + 127) / 128, d->H, d->B);
+    if (occ & 1) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q);
+        EGOMI_LAUNCH(attn_bwd_dq_kernel<2>, grid, dim3(256), lds_q, s, a);
+    } else {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q);
+        EGOMI_LAUNCH(attn_bwd_dq_kernel<1>, grid, dim3(256), lds_q, s, a);
+    }
+    const size_t lds_k = 3 * DKV_STAGE;
+    if (occ & 2) EGOMI_LAUNCH(attn_bwd_dkdv_kernel<2>, grid, dim3(256), lds_k, s, a);
+    else EGOMI_LAUNCH(attn_bwd_dkdv_kernel<1>, grid, dim3(256), lds_k, s, a);
     return egomi_launch_status();
 }
