@@ -90,21 +90,61 @@ __device__ __forceinline__ void tile_dma(const bf16_t* base, long long ld, int r
     }
 }
 
+
+// ---- head-dim generic forms (forward kernel: HD = 128 for the LLaMA layers, 64 for the PointBERT blocks).
+// HD = 64 rows are 128 B, two per 256-B bank row; its swizzle f(row) = ((row>>1)&1)<<2 | (row>>2)&3 keeps both the b128 row
+// reads (16 rows x one chunk -> 16 distinct 16-B slots) and the transposed reads (rows r, r+2 in different 64-B groups) conflict-free.
+template <int HD> __device__ __forceinline__ int swz(int row) {
+    return HD == 128 ? (((row & 3) << 2) | ((row >> 2) & 3)) : ((((row >> 1) & 1) << 2) | ((row >> 2) & 3));
+}
+template <int HD> __device__ __forceinline__ int sw_off_t(int row, int ch) { return 2 * HD * row + 16 * (ch ^ swz<HD>(row)); }
+template <int HD> __device__ __forceinline__ bf16x8 lds_row8_t(const char* tile, int row, int ch) {
+    return *reinterpret_cast<const bf16x8*>(tile + sw_off_t<HD>(row, ch));
+}
+template <int HD> __device__ __forceinline__ bf16x8 lds_tr8_t(const char* tile, int r0, int col0, int lane) {
+    const int half = lane >> 5, q = (lane >> 2) & 3, p = lane & 3;
+    const int col = col0 + 16 * ((lane >> 4) & 1) + 4 * p;
+    const int ch = col >> 3, within = (col & 7) * 2;
+    const int ra = r0 + 4 * half + q;
+    const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(tile + sw_off_t<HD>(ra, ch) + within));
+    const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(tile + sw_off_t<HD>(ra + 8, ch) + within));
+    bf16x8 r;
+    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+    r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+    return r;
+}
+// one wave instruction = 1 KiB of the LDS image = (512 / HD) rows
+template <int ROWS, int HD>
+__device__ __forceinline__ void tile_dma_t(const bf16_t* base, long long ld, int row0, int row_max, char* tile, int wave, int lane) {
+    constexpr int RPI = 512 / HD, CPR = HD / 8, IPW = ROWS / RPI / 4;
+#pragma unroll
+    for (int j = 0; j < IPW; ++j) {
+        const int rl = (wave * IPW + j) * RPI + lane / CPR;
+        const int ch = (lane % CPR) ^ swz<HD>(rl);
+        int r = row0 + rl;
+        r = r < row_max ? r : row_max;
+        __builtin_amdgcn_global_load_lds((gbl_void_t*)(base + (long long)r * ld + ch * 8),
+                                         (lds_void_t*)(tile + (wave * IPW + j) * 1024), 16, 0, 0);
+    }
+}
+
 // =================================================================================================
 // forward: grid (ceil(S/128), H, B), 4 waves x 32 queries, KV tiles of 64 keys, K/V double-buffered
 // in LDS by LDS-DMA (one tile in flight across the barrier: counted vmcnt + raw s_barrier)
 // =================================================================================================
 #define AT_MAXS 4096
+template <int HD>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
+    constexpr int TB = 64 * 2 * HD;                                    // bytes of one 64-key K or V tile
     extern __shared__ __attribute__((aligned(16))) char smem[];       // [2][K 16K | V 16K] + key mask bytes
-    char* sMask = smem + 2 * 2 * 64 * 256;
+    char* sMask = smem + 2 * 2 * TB;
     const int lane = threadIdx.x & 63, half = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int b = blockIdx.z, h = blockIdx.y, q0 = (gridDim.x - 1 - blockIdx.x) * 128;   // causal: longest blocks first
     const long long row_base = (long long)b * a.S;
-    const bf16_t* Q = a.q + row_base * a.ld_qkv + h * AT_HD;
-    const bf16_t* K = a.k + row_base * a.ld_qkv + h * AT_HD;
-    const bf16_t* V = a.v + row_base * a.ld_qkv + h * AT_HD;
+    const bf16_t* Q = a.q + row_base * a.ld_qkv + h * HD;
+    const bf16_t* K = a.k + row_base * a.ld_qkv + h * HD;
+    const bf16_t* V = a.v + row_base * a.ld_qkv + h * HD;
     const int qi = q0 + wave * 32 + (lane & 31);                      // this lane's query
     const int qr = qi < a.S ? qi : a.S - 1;
 
@@ -116,29 +156,30 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
         if (ok && a.key_mask) ok = a.key_mask[row_base + j] != 0;
         sMask[j] = ok;
     }
-    bf16x8 qf[8];
+    bf16x8 qf[HD / 16];
 #pragma unroll
-    for (int ks = 0; ks < 8; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(Q + (long long)qr * a.ld_qkv + 16 * ks + 8 * half);
+    for (int ks = 0; ks < HD / 16; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(Q + (long long)qr * a.ld_qkv + 16 * ks + 8 * half);
 
-    f32x16 o[4];
+    f32x16 o[HD / 32];
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt)
+    for (int dt = 0; dt < HD / 32; ++dt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;
     const float sc2 = a.scale * 1.4426950408889634f;
 
-    tile_dma<64>(K, a.ld_qkv, 0, a.S - 1, smem, wave, lane);
-    tile_dma<64>(V, a.ld_qkv, 0, a.S - 1, smem + 64 * 256, wave, lane);
+    tile_dma_t<64, HD>(K, a.ld_qkv, 0, a.S - 1, smem, wave, lane);
+    tile_dma_t<64, HD>(V, a.ld_qkv, 0, a.S - 1, smem + TB, wave, lane);
     for (int t = 0; t < ntiles; ++t) {
         const int kv0 = t * 64;
-        char* sK = smem + (t & 1) * (2 * 64 * 256);
-        char* sV = sK + 64 * 256;
+        char* sK = smem + (t & 1) * (2 * TB);
+        char* sV = sK + TB;
         if (t + 1 < ntiles) {
-            char* nK = smem + ((t + 1) & 1) * (2 * 64 * 256);
-            tile_dma<64>(K, a.ld_qkv, kv0 + 64, a.S - 1, nK, wave, lane);
-            tile_dma<64>(V, a.ld_qkv, kv0 + 64, a.S - 1, nK + 64 * 256, wave, lane);
-            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");           // tile t landed; tile t+1 (8 DMAs) stays in flight
+            char* nK = smem + ((t + 1) & 1) * (2 * TB);
+            tile_dma_t<64, HD>(K, a.ld_qkv, kv0 + 64, a.S - 1, nK, wave, lane);
+            tile_dma_t<64, HD>(V, a.ld_qkv, kv0 + 64, a.S - 1, nK + TB, wave, lane);
+            if (HD == 128) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");           // tile t landed; tile t+1 (8 DMAs) stays in flight
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
@@ -162,8 +203,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) x[r] = 0.f;
 #pragma unroll
-            for (int ks = 0; ks < 8; ++ks)
-                x = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_row8(sK, 32 * sub + (lane & 31), 2 * ks + half), qf[ks], x, 0, 0, 0);
+            for (int ks = 0; ks < HD / 16; ++ks)
+                x = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_row8_t<HD>(sK, 32 * sub + (lane & 31), 2 * ks + half), qf[ks], x, 0, 0, 0);
             // raw scores stay in s[][] (the scale is folded into the exp); masks only where the sub-tile needs them
             const bool interior = ((kmask >> (32 * sub)) & 0xFFFFFFFFull) == 0xFFFFFFFFull &&
                                   (!a.causal || kv0 + 32 * sub + 31 <= q0 + wave * 32);       // wave-uniform
@@ -199,7 +240,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
         m_run = m_new;
         if (!__all(alpha == 1.0f)) {                                   // running max unchanged for the whole wave: O keeps its scale
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt)
+            for (int dt = 0; dt < HD / 32; ++dt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
         }
@@ -210,8 +251,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
             for (int st = 0; st < 2; ++st) {
                 const bf16x8 pb = pack8(&s[sub][8 * st]);
 #pragma unroll
-                for (int dt = 0; dt < 4; ++dt)
-                    o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_tr8(sV, 32 * sub + 16 * st, 32 * dt, lane), pb, o[dt], 0, 0, 0);
+                for (int dt = 0; dt < HD / 32; ++dt)
+                    o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_tr8_t<HD>(sV, 32 * sub + 16 * st, 32 * dt, lane), pb, o[dt], 0, 0, 0);
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -219,9 +260,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
     }
     if (qi < a.S) {
         const float inv = l_run > 0.f ? 1.0f / l_run : 0.f;
-        bf16_t* orow = a.o + (row_base + qi) * a.ld_o + h * AT_HD;
+        bf16_t* orow = a.o + (row_base + qi) * a.ld_o + h * HD;
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt)
+        for (int dt = 0; dt < HD / 32; ++dt)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 u32x2 w;
@@ -546,11 +587,12 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_dkdv_kernel(AttnArgs a) {
     }
 }
 
-static int attn_check(const egomi_attn_desc* d) {
+static int attn_check(const egomi_attn_desc* d, bool fwd_only = false) {
     if (!d || !d->q || !d->k || !d->v) return EGOMI_E_BADARG;
-    if (d->B <= 0 || d->H <= 0 || d->S <= 0 || d->head_dim != AT_HD) return d && d->head_dim != AT_HD ? EGOMI_E_UNSUPPORTED : EGOMI_E_SHAPE;
+    if (d->head_dim != AT_HD && !(fwd_only && d->head_dim == 64)) return EGOMI_E_UNSUPPORTED;
+    if (d->B <= 0 || d->H <= 0 || d->S <= 0) return EGOMI_E_SHAPE;
     if (d->dtype != EGOMI_BF16) return EGOMI_E_UNSUPPORTED;
-    if (d->ld_qkv % 8 || d->ld_qkv < AT_HD * d->H) return EGOMI_E_SHAPE;
+    if (d->ld_qkv % 8 || d->ld_qkv < d->head_dim * d->H) return EGOMI_E_SHAPE;
     if (((uintptr_t)d->q | (uintptr_t)d->k | (uintptr_t)d->v) & 15) return EGOMI_E_SHAPE;
     return EGOMI_OK;
 }
@@ -565,14 +607,19 @@ static AttnArgs attn_args(const egomi_attn_desc* d) {
 }
 
 extern "C" int egomi_attn_fwd(const egomi_attn_desc* d, egomi_stream_t stream) {
-    const int rc = attn_check(d);
+    const int rc = attn_check(d, true);
     if (rc) return rc;
-    if (!d->o || d->ld_o % 4 || d->ld_o < AT_HD * d->H || ((uintptr_t)d->o & 7)) return EGOMI_E_SHAPE;
+    if (!d->o || d->ld_o % 4 || d->ld_o < d->head_dim * d->H || ((uintptr_t)d->o & 7)) return EGOMI_E_SHAPE;
     if (d->S > AT_MAXS) return EGOMI_E_UNSUPPORTED;
     AttnArgs a = attn_args(d);
-    const size_t lds = 2 * 2 * 64 * 256 + (size_t)((d->S + 63) / 64) * 64;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    EGOMI_LAUNCH(attn_fwd_kernel, dim3((d->S + 127) / 128, d->H, d->B), dim3(256), lds, (hipStream_t)stream, a);
+    const dim3 grid((d->S + 127) / 128, d->H, d->B);
+    const size_t lds = 2 * 2 * 64 * 2 * (size_t)d->head_dim + (size_t)((d->S + 63) / 64) * 64;
+    if (d->head_dim == 128) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        EGOMI_LAUNCH(attn_fwd_kernel<128>, grid, dim3(256), lds, (hipStream_t)stream, a);
+    } else {
+        EGOMI_LAUNCH(attn_fwd_kernel<64>, grid, dim3(256), lds, (hipStream_t)stream, a);
+    }
     return egomi_launch_status();
 }
 

@@ -219,7 +219,10 @@ class Engine:
             p = f"{pre}blocks.blocks.{i}."
             ops.layernorm(xf, w[p + "norm1.weight"], w[p + "norm1.bias"], pb.ln_eps, add=pos.view(M, D), sum_out=xs, out=h)
             ops.mm(h, w[p + "attn.qkv.weight"], out=qkv)
-            self._attention(qkv, B, Pn, H, hd, ao, False, None, hd ** -0.5, False)
+            if self.use_fused_attention and T == torch.bfloat16 and hd == 64:
+                ops.attn_fwd(qkv, B, Pn, H, hd, hd ** -0.5, ao, None, causal=False)       # scores never reach HBM
+            else:
+                self._attention(qkv, B, Pn, H, hd, ao, False, None, hd ** -0.5, False)
             ops.mm(ao, w[p + "attn.proj.weight"], out=x1, bias=w[p + "attn.proj.bias"], residual=xs)
             ops.layernorm(x1, w[p + "norm2.weight"], w[p + "norm2.bias"], pb.ln_eps, out=h)
             ops.mm(h, w[p + "mlp.fc1.weight"], out=mid, bias=w[p + "mlp.fc1.bias"], act=ops.ACT_GELU)

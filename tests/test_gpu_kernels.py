@@ -332,6 +332,26 @@ def test_fused_attention_forward(ops, B, S, H, causal, masked):
     assert float((lse.cpu() - lse_ref).abs().max()) < 2e-2
 
 
+@pytest.mark.parametrize("B,S,H,causal,masked", [(2, 513, 6, False, False), (1, 65, 2, False, True), (2, 200, 3, True, True), (1, 1, 1, False, False)])
+def test_fused_attention_forward_hd64(ops, B, S, H, causal, masked):
+    """head_dim 64 instance of the forward kernel (PointBERT blocks, point_encoder.py:36-57: 513 tokens, 6 heads, no mask)."""
+    hd = 64
+    qkv = rnd(B * S, 3 * H * hd, dtype=torch.bfloat16, seed=S + 7)
+    km = None
+    if masked:
+        km = torch.ones(B, S, dtype=torch.uint8)
+        km[-1, S - S // 5:] = 0
+    ref, lse_ref = _ref_attention(qkv, B, S, H, hd, hd ** -0.5, causal, km)
+    out = torch.zeros(B * S, H * hd, dtype=torch.bfloat16, device="cuda")
+    lse = torch.zeros(B, H, S, dtype=torch.float32, device="cuda")
+    ops.attn_fwd(qkv.cuda(), B, S, H, hd, hd ** -0.5, out, lse, causal=causal, key_mask=None if km is None else km.cuda())
+    close(out, ref, 2e-2)
+    assert float((lse.cpu() - lse_ref).abs().max()) < 2e-2
+    out2 = torch.zeros_like(out)
+    ops.attn_fwd(qkv.cuda(), B, S, H, hd, hd ** -0.5, out2, None, causal=causal, key_mask=None if km is None else km.cuda())   # LSE optional
+    assert torch.equal(out, out2)
+
+
 @pytest.mark.parametrize("B,S,H,causal,masked", [(2, 200, 3, True, True), (1, 692, 2, True, False), (2, 64, 1, False, True), (1, 33, 2, True, False), (1, 300, 1, True, True)])
 def test_fused_attention_backward(ops, B, S, H, causal, masked):
     hd = 128
