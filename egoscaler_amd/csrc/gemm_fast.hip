@@ -499,7 +499,8 @@ static int tile_choice(const egomi_gemm_desc* d) {
 
 extern "C" int egomi_gemm_kernel_id(const egomi_gemm_desc* d) {
     if (!d) return EGOMI_E_BADARG;
-    return (!d->force_generic && fast_applicable(d)) ? 1 : 0;
+    if (d->force_generic || !fast_applicable(d)) return 0;
+    return tile_choice(d) == 8 ? 2 : 1;
 }
 
 template <int BM, int BN, int DB, int MT = 4>

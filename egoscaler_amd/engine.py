@@ -46,6 +46,7 @@ class Engine:
         self.dims, self.w, self.device, self.dtype = dims, params, device, dtype
         self.ws = Workspace(device)
         self.prepared = False
+        self.lm_wT, self.lm_wT_stale, self.lm_wT_ver = None, True, None     # padded transpose of lm_head for its dgrad (backward_logits)
         self.main_grad: Dict[str, torch.Tensor] = {}     # fp32 gradient buffers of trainable tensors
         self.trainable: Dict[str, bool] = {}
         self.ctx = None
@@ -110,6 +111,7 @@ class Engine:
     def after_weights_update(self):
         """Called by the optimizer after a step: the resident W^T of TRAINABLE decoder weights must
         follow the new values (a 2-byte transpose pass per weight; frozen ones never change)."""
+        self.lm_wT_stale = True
         if not self.prepared:
             return
         if self.pb_trainable:
@@ -356,10 +358,18 @@ class Engine:
             self.ctx = ctx
         return hn
 
-    def logits(self, hn, rows=None):
-        """lm_head (pointllm.py:227-228).  hn [M,d] -> [M,V]."""
+    def logits(self, hn, rows=None, padded=False):
+        """lm_head (pointllm.py:227-228).  hn [M,d] -> [M,V].  padded=True (training step): the result is a view of a
+        [M, V64] buffer (V rounded up to 64, pad columns zero) so that the lm_head dgrad can run K-contiguous on the
+        tuned kernel with K = V64 (V = 32003 + new tokens is odd: rows of a dense [M,V] array are not even 4-B aligned)."""
         W = self.w["lm_head.weight"]
-        return ops.mm(hn, W, out=torch.empty(hn.shape[0], W.shape[0], dtype=self.dtype, device=self.device))
+        M, V = hn.shape[0], W.shape[0]
+        if padded and self.dtype == torch.bfloat16:
+            Vp = (V + 63) // 64 * 64
+            buf = torch.empty(M, Vp, dtype=self.dtype, device=self.device)
+            buf[:, V:].zero_()
+            return ops.mm(hn, W, out=buf[:, :V])
+        return ops.mm(hn, W, out=torch.empty(M, V, dtype=self.dtype, device=self.device))
 
     @property
     def pb_trainable(self):
@@ -494,7 +504,20 @@ class Engine:
     def backward_logits(self, d_logits, hn):
         """lm_head backward: d_hn = d_logits . W ; dW += d_logits^T . hn."""
         W = self.w["lm_head.weight"]
-        d_hn = ops.mm(d_logits, W, out=self.ws.get("d_hn", hn.shape, self.dtype), b_layout=1)
+        V, d = W.shape
+        Vp = (V + 63) // 64 * 64
+        if self.dtype == torch.bfloat16 and d_logits.dim() == 2 and d_logits.stride(0) == Vp and d_logits.stride(1) == 1:
+            # padded logits (see logits()): resident [d, V64] transpose of the head, refreshed after every optimizer step
+            if self.lm_wT is None or self.lm_wT.shape != (d, Vp):
+                self.lm_wT = torch.zeros(d, Vp, dtype=self.dtype, device=self.device)
+                self.lm_wT_stale = True
+            if self.lm_wT_stale or self.lm_wT_ver != (W.data_ptr(), W._version):     # EgoAdamW flags it; torch optimizers bump _version
+                ops.transpose(W, ldo=Vp, out=self.lm_wT)
+                self.lm_wT_stale, self.lm_wT_ver = False, (W.data_ptr(), W._version)
+            d_hn = ops.mm(torch.as_strided(d_logits, (d_logits.shape[0], Vp), (Vp, 1)), self.lm_wT,
+                          out=self.ws.get("d_hn", hn.shape, self.dtype))
+        else:
+            d_hn = ops.mm(d_logits, W, out=self.ws.get("d_hn", hn.shape, self.dtype), b_layout=1)
         self._wgrad("lm_head.weight", d_logits, hn)
         self._notify("lm_head.weight")
         return d_hn

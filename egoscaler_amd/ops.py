@@ -114,8 +114,10 @@ ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
 class GemmProfiler:
     """HIP-event timing of GEMM launches on the stream they are launched on (bench.py roofline)."""
 
-    def __init__(self, min_flops=1e9, tuned_only=True):
+    def __init__(self, min_flops=1e9, tuned_only=True, kernel_ids=None):
+        """kernel_ids: egomi_gemm_kernel_id() values to record (None: 1 and 2 when tuned_only, else everything)."""
         self.min_flops, self.recs, self.enabled, self.tuned_only = min_flops, [], True, tuned_only
+        self.kernel_ids = kernel_ids if kernel_ids is not None else ((1, 2) if tuned_only else None)
 
     def summary(self):
         torch.cuda.synchronize()
@@ -173,7 +175,7 @@ def gemm_raw(A, B, C, M, N, K, lda, ldb, ldc, a_layout=0, b_layout=0, bias=None,
     prof = PROFILER
     flops = 2.0 * M * N * K * max(1, batch)
     if prof is not None and prof.enabled and flops >= prof.min_flops and \
-            (not prof.tuned_only or _lib.lib().egomi_gemm_kernel_id(ctypes.byref(d)) == 1):
+            (prof.kernel_ids is None or _lib.lib().egomi_gemm_kernel_id(ctypes.byref(d)) in prof.kernel_ids):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         call("egomi_gemm", ctypes.byref(d), S())

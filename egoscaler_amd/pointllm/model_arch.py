@@ -336,7 +336,7 @@ class TrajPointLLMForCausalLM(nn.Module):
         Lp = int(prompt_len)
         hs = hn.view(B, S, d)[:, Lp - 1:S - 1].reshape(-1, d)
         tg = input_ids[:, Lp:].reshape(-1).contiguous()
-        lg = eng.logits(hs)
+        lg = eng.logits(hs, padded=backward)
         ls, cnt = ops.cross_entropy(lg, tg, pad_token_id, dlogits=lg if backward else None, grad_scale=grad_scale)
         loss = ls / cnt.float()
         if backward:

@@ -111,12 +111,15 @@ typedef struct egomi_gemm_desc {
     int accumulate;
     int act;
     int force_generic;   /* 1: never take the tuned kernel (used by tests to cross-check it) */
-    /* optional split-K for skinny products (M <= 512, e.g. single-token decode): fp32 scratch of at least
-     * split_k * M * N * 4 bytes; split_k 0 = chosen by the library from the tile count.  NULL = no split. */
+    /* optional fp32 scratch.  Skinny products (M <= 512, e.g. single-token decode): split-K slabs of split_k * M * N * 4
+     * bytes; split_k 0 = chosen by the library from the tile count.  Large products (256x256 kernel): the last tile rows
+     * are cut into K-slices so the ragged last round fills the chip; their slabs live here too (split_k 0 = planned by
+     * the library, rows*16+S = explicit).  NULL = neither. */
     void* workspace; int64_t workspace_bytes; int split_k;
 } egomi_gemm_desc;
 int egomi_gemm(const egomi_gemm_desc* desc, egomi_stream_t stream);
-/* which kernel egomi_gemm would run for this descriptor: 1 = tuned bf16 NT kernel, 0 = generic */
+/* which kernel egomi_gemm would run for this descriptor: 2 = 256x256 8-phase bf16 NT kernel, 1 = 128x128 / 256x128 bf16
+ * NT kernel, 0 = generic */
 int egomi_gemm_kernel_id(const egomi_gemm_desc* desc);
 
 /* ------------------------------------------------------------------------------------------------
