@@ -128,6 +128,33 @@ __device__ __forceinline__ void tile_dma_t(const bf16_t* base, long long ld, int
     }
 }
 
+
+// ---- epilogue rows through LDS.  The 32x32 accumulators hold, per lane, one row (query or key = lane & 31) and 4-element
+// pieces of its 128 values, so a direct store instruction scatters 8-B pieces over 32 rows of a [*, ld] array (measured:
+// 17 us of the 153-us dQ kernel).  Each wave instead drops its 32 x 128 bf16 block into a private LDS region (272-B row
+// pitch: the 8-B writes of 32 rows spread over the banks) and stores it back as whole 256-B rows, 16 B per lane.
+#define AT_XPITCH 272
+#define AT_XBYTES (32 * AT_XPITCH)
+__device__ __forceinline__ void store_rows_via_lds(char* wbuf, const f32x16 (&acc)[4], const float mul, bf16_t* gbase, const long long ld,
+                                                   const int row0, const int nrows, const int lane) {
+    const int half = lane >> 5, rl = lane & 31;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            u32x2 w;
+            w[0] = (uint32_t)f2bf(acc[dt][4 * g] * mul) | ((uint32_t)f2bf(acc[dt][4 * g + 1] * mul) << 16);
+            w[1] = (uint32_t)f2bf(acc[dt][4 * g + 2] * mul) | ((uint32_t)f2bf(acc[dt][4 * g + 3] * mul) << 16);
+            *reinterpret_cast<u32x2*>(wbuf + rl * AT_XPITCH + (32 * dt + 8 * g + 4 * half) * 2) = w;
+        }
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int r = it * 4 + (lane >> 4), ch = lane & 15;
+        const u32x4 v = *reinterpret_cast<const u32x4*>(wbuf + r * AT_XPITCH + ch * 16);
+        if (row0 + r < nrows) *reinterpret_cast<u32x4*>(gbase + (long long)(row0 + r) * ld + ch * 8) = v;
+    }
+}
+
 // =================================================================================================
 // forward: grid (ceil(S/128), H, B), 4 waves x 32 queries, KV tiles of 64 keys, K/V double-buffered
 // in LDS by LDS-DMA (one tile in flight across the barrier: counted vmcnt + raw s_barrier)
@@ -258,7 +285,15 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                                  // buffer (t&1) is free for the DMA of tile t+2
     }
-    if (qi < a.S) {
+    if (HD == 128) {
+        if constexpr (HD == 128) {
+            // whole 256-B rows through the (now idle) stages; the loop ended on a barrier with no DMA outstanding
+            const float inv = l_run > 0.f ? 1.0f / l_run : 0.f;
+            store_rows_via_lds(smem + wave * AT_XBYTES, o, inv, a.o + row_base * a.ld_o + h * HD, a.ld_o, q0 + wave * 32, a.S, lane);
+        }
+        if (qi < a.S && half == 0 && a.lse)
+            a.lse[((long long)b * a.H + h) * a.S + qi] = (m_run == -INFINITY) ? INFINITY : m_run * 0.6931471805599453f + logf(l_run);
+    } else if (qi < a.S) {
         const float inv = l_run > 0.f ? 1.0f / l_run : 0.f;
         bf16_t* orow = a.o + (row_base + qi) * a.ld_o + h * HD;
 #pragma unroll
@@ -438,19 +473,9 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_dq_kernel(AttnArgs a) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // the tail's redundant DMAs land before the block's LDS is released
-    if (qi < a.S) {
-        bf16_t* orow = a.dq + (row_base + qi) * a.ld_dqkv + h * AT_HD;
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                u32x2 w;
-                w[0] = (uint32_t)f2bf(dq[dt][4 * g] * a.scale) | ((uint32_t)f2bf(dq[dt][4 * g + 1] * a.scale) << 16);
-                w[1] = (uint32_t)f2bf(dq[dt][4 * g + 2] * a.scale) | ((uint32_t)f2bf(dq[dt][4 * g + 3] * a.scale) << 16);
-                *reinterpret_cast<u32x2*>(orow + 32 * dt + 8 * g + 4 * half) = w;
-            }
-    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // the tail's redundant DMAs have landed ...
+    __builtin_amdgcn_s_barrier();                                     // ... for every wave: the stages are free for the row exchange
+    store_rows_via_lds(smem + wave * AT_XBYTES, dq, a.scale, a.dq + row_base * a.ld_dqkv + h * AT_HD, a.ld_dqkv, q0 + wave * 32, a.S, lane);
 }
 
 // =================================================================================================
@@ -569,22 +594,9 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_dkdv_kernel(AttnArgs a) {
         __builtin_amdgcn_s_barrier();
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (kj < a.S) {
-        bf16_t* krow = a.dk + (row_base + kj) * a.ld_dqkv + h * AT_HD;
-        bf16_t* vrow = a.dv + (row_base + kj) * a.ld_dqkv + h * AT_HD;
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                u32x2 w;
-                w[0] = (uint32_t)f2bf(dk[dt][4 * g] * a.scale) | ((uint32_t)f2bf(dk[dt][4 * g + 1] * a.scale) << 16);
-                w[1] = (uint32_t)f2bf(dk[dt][4 * g + 2] * a.scale) | ((uint32_t)f2bf(dk[dt][4 * g + 3] * a.scale) << 16);
-                *reinterpret_cast<u32x2*>(krow + 32 * dt + 8 * g + 4 * half) = w;
-                w[0] = (uint32_t)f2bf(dv[dt][4 * g]) | ((uint32_t)f2bf(dv[dt][4 * g + 1]) << 16);
-                w[1] = (uint32_t)f2bf(dv[dt][4 * g + 2]) | ((uint32_t)f2bf(dv[dt][4 * g + 3]) << 16);
-                *reinterpret_cast<u32x2*>(vrow + 32 * dt + 8 * g + 4 * half) = w;
-            }
-    }
+    __builtin_amdgcn_s_barrier();
+    store_rows_via_lds(smem + wave * AT_XBYTES, dk, a.scale, a.dk + row_base * a.ld_dqkv + h * AT_HD, a.ld_dqkv, kb0 + wave * 32, a.S, lane);
+    store_rows_via_lds(smem + wave * AT_XBYTES, dv, 1.0f, a.dv + row_base * a.ld_dqkv + h * AT_HD, a.ld_dqkv, kb0 + wave * 32, a.S, lane);
 }
 
 static int attn_check(const egomi_attn_desc* d, bool fwd_only = false) {
@@ -609,7 +621,7 @@ static AttnArgs attn_args(const egomi_attn_desc* d) {
 extern "C" int egomi_attn_fwd(const egomi_attn_desc* d, egomi_stream_t stream) {
     const int rc = attn_check(d, true);
     if (rc) return rc;
-    if (!d->o || d->ld_o % 4 || d->ld_o < d->head_dim * d->H || ((uintptr_t)d->o & 7)) return EGOMI_E_SHAPE;
+    if (!d->o || d->ld_o % 8 || d->ld_o < d->head_dim * d->H || ((uintptr_t)d->o & 15)) return EGOMI_E_SHAPE;
     if (d->S > AT_MAXS) return EGOMI_E_UNSUPPORTED;
     AttnArgs a = attn_args(d);
     const dim3 grid((d->S + 127) / 128, d->H, d->B);
@@ -627,8 +639,8 @@ extern "C" int egomi_attn_bwd(const egomi_attn_desc* d, egomi_stream_t stream) {
     const int rc = attn_check(d);
     if (rc) return rc;
     if (!d->o || !d->lse || !d->dout || !d->delta || !d->dq || !d->dk || !d->dv) return EGOMI_E_BADARG;
-    if (d->ld_o % 8 || d->ld_dqkv % 4 || d->ld_o < AT_HD * d->H || d->ld_dqkv < AT_HD * d->H) return EGOMI_E_SHAPE;
-    if (((uintptr_t)d->dout & 15) || (((uintptr_t)d->dq | (uintptr_t)d->dk | (uintptr_t)d->dv) & 7) || ((uintptr_t)d->o & 15)) return EGOMI_E_SHAPE;
+    if (d->ld_o % 8 || d->ld_dqkv % 8 || d->ld_o < AT_HD * d->H || d->ld_dqkv < AT_HD * d->H) return EGOMI_E_SHAPE;
+    if (((uintptr_t)d->dout & 15) || (((uintptr_t)d->dq | (uintptr_t)d->dk | (uintptr_t)d->dv) & 15) || ((uintptr_t)d->o & 15)) return EGOMI_E_SHAPE;
     if (d->S > AT_MAXS) return EGOMI_E_UNSUPPORTED;
     AttnArgs a = attn_args(d);
     hipStream_t s = (hipStream_t)stream;
