@@ -340,7 +340,8 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* dout, con
 template <int OCC>
 __global__ __launch_bounds__(256, OCC) void attn_bwd_dq_kernel(AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* sMask = smem + 3 * 2 * 64 * 256;                           // three K|V stages: two tiles stay in flight (one wave per SIMD, nothing else hides the DMA latency)
+    constexpr int NST = OCC == 2 ? 2 : 3;                             // K|V stages: OCC 2 = two blocks per CU (64 KB each), else three stages for the lone wave per SIMD
+    char* sMask = smem + NST * 2 * 64 * 256;
     const int lane = threadIdx.x & 63, half = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int b = blockIdx.z, h = blockIdx.y, q0 = (gridDim.x - 1 - blockIdx.x) * 128;   // causal: longest blocks are dispatched first
@@ -374,14 +375,13 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_dq_kernel(AttnArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) dq[dt][r] = 0.f;
 
-    // tiles 0 and 1 in flight before the loop; past the last tile the DMA re-loads it into a stage nobody reads any more,
+    // NST-1 tiles in flight before the loop; past the last tile the DMA re-loads it into a stage nobody reads any more,
     // which keeps the vmcnt arithmetic constant (8 DMAs per tile and wave)
-    {
-        const int t1 = 1 < ntiles ? 1 : ntiles - 1;
-        tile_dma<64>(K, a.ld_qkv, 0, a.S - 1, smem, wave, lane);
-        tile_dma<64>(V, a.ld_qkv, 0, a.S - 1, smem + 64 * 256, wave, lane);
-        tile_dma<64>(K, a.ld_qkv, t1 * 64, a.S - 1, smem + 2 * 64 * 256, wave, lane);
-        tile_dma<64>(V, a.ld_qkv, t1 * 64, a.S - 1, smem + 3 * 64 * 256, wave, lane);
+#pragma unroll
+    for (int i = 0; i < NST - 1; ++i) {
+        const int ti = i < ntiles ? i : ntiles - 1;
+        tile_dma<64>(K, a.ld_qkv, ti * 64, a.S - 1, smem + i * (2 * 64 * 256), wave, lane);
+        tile_dma<64>(V, a.ld_qkv, ti * 64, a.S - 1, smem + i * (2 * 64 * 256) + 64 * 256, wave, lane);
     }
     int stg = 0;
     for (int t = 0; t < ntiles; ++t) {
@@ -389,53 +389,18 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_dq_kernel(AttnArgs a) {
         char* sK = smem + stg * (2 * 64 * 256);
         char* sV = sK + 64 * 256;
         {
-            const int t2 = t + 2 < ntiles ? t + 2 : ntiles - 1;
-            const int s2 = stg >= 1 ? stg - 1 : 2;                     // (stg + 2) % 3
+            const int t2 = t + NST - 1 < ntiles ? t + NST - 1 : ntiles - 1;
+            const int s2 = stg >= 1 ? stg - 1 : NST - 1;               // (stg + NST - 1) % NST
             char* nK = smem + s2 * (2 * 64 * 256);
             tile_dma<64>(K, a.ld_qkv, t2 * 64, a.S - 1, nK, wave, lane);
             tile_dma<64>(V, a.ld_qkv, t2 * 64, a.S - 1, nK + 64 * 256, wave, lane);
-            asm volatile("s_waitcnt vmcnt(16)" ::: "memory");          // tile t landed; tiles t+1, t+2 stay in flight
+            if (NST == 3) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");   // tile t landed; the later ones stay in flight
+            else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         }
-        stg = stg == 2 ? 0 : stg + 1;
+        stg = stg == NST - 1 ? 0 : stg + 1;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         const unsigned long long kmask = __ballot(sMask[kv0 + lane] != 0);
-        if (kmask == ~0ull && (!a.causal || kv0 + 63 <= q0 + wave * 32)) {
-            // interior tile (no mask anywhere): straight-line code, both 32-key halves in one block so the scores / dP
-            // products of the second half and the dQ products of the first run under the other half's exp/dS arithmetic
-            f32x16 x0, dp0, x1, dp1;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { x0[r] = 0.f; dp0[r] = 0.f; x1[r] = 0.f; dp1[r] = 0.f; }
-#pragma unroll
-            for (int ks = 0; ks < 8; ++ks) {
-                x0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_row8(sK, lane & 31, 2 * ks + half), qf[ks], x0, 0, 0, 0);
-                dp0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_row8(sV, lane & 31, 2 * ks + half), dof[ks], dp0, 0, 0, 0);
-            }
-#pragma unroll
-            for (int ks = 0; ks < 8; ++ks) {
-                x1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_row8(sK, 32 + (lane & 31), 2 * ks + half), qf[ks], x1, 0, 0, 0);
-                dp1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_row8(sV, 32 + (lane & 31), 2 * ks + half), dof[ks], dp1, 0, 0, 0);
-            }
-            float ds0[16], ds1[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) ds0[r] = fast_exp2(fmaf(x0[r], sc2, -lse2)) * (dp0[r] - dlt);
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-                const bf16x8 db = pack8(&ds0[8 * s2]);
-#pragma unroll
-                for (int dt = 0; dt < 4; ++dt)
-                    dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_tr8(sK, 16 * s2, 32 * dt, lane), db, dq[dt], 0, 0, 0);
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) ds1[r] = fast_exp2(fmaf(x1[r], sc2, -lse2)) * (dp1[r] - dlt);
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-                const bf16x8 db = pack8(&ds1[8 * s2]);
-#pragma unroll
-                for (int dt = 0; dt < 4; ++dt)
-                    dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_tr8(sK, 32 + 16 * s2, 32 * dt, lane), db, dq[dt], 0, 0, 0);
-            }
-        } else
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
             if (a.causal && (kv0 + 32 * sub > q0 + wave * 32 + 31)) continue;       // wave-uniform: every P of this sub-tile is 0
@@ -599,6 +564,15 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_dkdv_kernel(AttnArgs a) {
     store_rows_via_lds(smem + wave * AT_XBYTES, dv, 1.0f, a.dv + row_base * a.ld_dqkv + h * AT_HD, a.ld_dqkv, kb0 + wave * 32, a.S, lane);
 }
 
+// dQ kernel at two blocks per CU (234 VGPRs, two 32-KB K|V stages) unless EGOMI_ATTN_OCC says otherwise (bit 0 clear = one
+// block per CU with three stages; bit 1 = two-wave dK/dV build, which spills)
+static int attn_occ() {
+    static int occ = -1;
+    if (occ < 0) { const char* e = getenv("EGOMI_ATTN_OCC"); occ = e ? atoi(e) : 1; }
+    return occ;
+}
+static bool occ_dq2() { return attn_occ() & 1; }
+
 static int attn_check(const egomi_attn_desc* d, bool fwd_only = false) {
     if (!d || !d->q || !d->k || !d->v) return EGOMI_E_BADARG;
     if (d->head_dim != AT_HD && !(fwd_only && d->head_dim == 64)) return EGOMI_E_UNSUPPORTED;
@@ -646,9 +620,8 @@ extern "C" int egomi_attn_bwd(const egomi_attn_desc* d, egomi_stream_t stream) {
     hipStream_t s = (hipStream_t)stream;
     const long long items = (long long)d->B * d->S * d->H;
     EGOMI_LAUNCH(attn_delta_kernel, dim3((unsigned)((items + 15) / 16)), dim3(256), 0, s, a.dout, (const bf16_t*)d->o, d->delta, d->B, d->H, d->S, d->ld_o);
-    const size_t lds_q = 3 * 2 * 64 * 256 + (size_t)((d->S + 63) / 64) * 64;
-    static int occ = -1;                                               // A/B switch: bit 0 / bit 1 = two waves per SIMD for dQ / dKdV
-    if (occ < 0) { const char* e = getenv("EGOMI_ATTN_OCC"); occ = e ? atoi(e) : 0; }
+    const size_t lds_q = ((occ_dq2() ? 2 : 3) * 2 * 64 * 256) + (size_t)((d->S + 63) / 64) * 64;
+    const int occ = attn_occ();
     const dim3 grid((d->S + 127) / 128, d->H, d->B);
     if (occ & 1) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q);
