@@ -468,11 +468,16 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_dkdv_kernel(AttnArgs a) {
     bool key_ok = kj < a.S;
     if (key_ok && a.key_mask) key_ok = a.key_mask[row_base + kj] != 0;
     const bool keys_all_ok = __all(key_ok);
-    bf16x8 kf[8], vf[8];
+    // OCC 2 (two blocks per CU, <= 256 registers): two stages, and the block's 128 V rows live in LDS (32 KB, read per tile)
+    // instead of 32 registers per lane; OCC 1: three stages, V fragments in registers
+    constexpr int NST = OCC == 2 ? 2 : 3;
+    char* sVblk = smem + NST * DKV_STAGE;
+    bf16x8 kf[8], vf[OCC == 2 ? 1 : 8];
+    if (OCC == 2) tile_dma<128>(V, a.ld_qkv, kb0, a.S - 1, sVblk, wave, lane);
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) {
         kf[ks] = *reinterpret_cast<const bf16x8*>(K + (long long)kr * a.ld_qkv + 16 * ks + 8 * half);
-        vf[ks] = *reinterpret_cast<const bf16x8*>(V + (long long)kr * a.ld_qkv + 16 * ks + 8 * half);
+        if (OCC != 2) vf[ks] = *reinterpret_cast<const bf16x8*>(V + (long long)kr * a.ld_qkv + 16 * ks + 8 * half);
     }
     f32x16 dk[4], dv[4];
 #pragma unroll
@@ -492,19 +497,20 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_dkdv_kernel(AttnArgs a) {
         const float* src = (wave & 1) ? (DEL + qq) : (LSE + qq);
         __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(stage + 2 * 32 * 256 + wave * 256), 4, 0, 0);
     };
-    // three stages, two query tiles in flight (one wave per SIMD: nothing else hides the DMA latency); past the last tile
-    // the DMA re-loads it into a stage nobody reads any more, which keeps the vmcnt arithmetic constant (5 DMAs per tile)
+    // NST stages, NST-1 query tiles in flight; past the last tile the DMA re-loads it into a stage nobody reads any more,
+    // which keeps the vmcnt arithmetic constant (5 DMAs per tile)
     if (qt0 < nq) {
-        issue(qt0, smem);
-        issue(qt0 + 1 < nq ? qt0 + 1 : nq - 1, smem + DKV_STAGE);
+#pragma unroll
+        for (int i = 0; i < NST - 1; ++i) issue(qt0 + i < nq ? qt0 + i : nq - 1, smem + i * DKV_STAGE);
     }
     int stg = 0;
     for (int qt = qt0; qt < nq; ++qt) {
         const int q0 = qt * 32;
         char* st = smem + stg * DKV_STAGE;
-        issue(qt + 2 < nq ? qt + 2 : nq - 1, smem + (stg >= 1 ? stg - 1 : 2) * DKV_STAGE);
-        asm volatile("s_waitcnt vmcnt(10)" ::: "memory");              // tile qt landed; 2 x (2 + 2 + 1) DMAs stay in flight
-        stg = stg == 2 ? 0 : stg + 1;
+        issue(qt + NST - 1 < nq ? qt + NST - 1 : nq - 1, smem + (stg >= 1 ? stg - 1 : NST - 1) * DKV_STAGE);
+        if (NST == 3) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");  // tile qt landed; (NST-1) x (2 + 2 + 1) DMAs stay in flight
+        else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        stg = stg == NST - 1 ? 0 : stg + 1;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         const char* sQ = st;
@@ -517,7 +523,8 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_dkdv_kernel(AttnArgs a) {
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) {
             x = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_row8(sQ, lane & 31, 2 * ks + half), kf[ks], x, 0, 0, 0);
-            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_row8(sDO, lane & 31, 2 * ks + half), vf[ks], dp, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_row8(sDO, lane & 31, 2 * ks + half),
+                                                         OCC == 2 ? lds_row8(sVblk, wave * 32 + (lane & 31), 2 * ks + half) : vf[OCC == 2 ? 0 : ks], dp, 0, 0, 0);
         }
         float pv[16], ds[16];
         // masks only on edge tiles: every key of the wave visible, every query of the tile in range and (causal) not before any key
@@ -564,11 +571,12 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_dkdv_kernel(AttnArgs a) {
     store_rows_via_lds(smem + wave * AT_XBYTES, dv, 1.0f, a.dv + row_base * a.ld_dqkv + h * AT_HD, a.ld_dqkv, kb0 + wave * 32, a.S, lane);
 }
 
-// dQ kernel at two blocks per CU (234 VGPRs, two 32-KB K|V stages) unless EGOMI_ATTN_OCC says otherwise (bit 0 clear = one
-// block per CU with three stages; bit 1 = two-wave dK/dV build, which spills)
+// Both backward kernels run at two blocks per CU (<= 256 VGPRs: dQ 234; dK/dV 256 with its V rows in LDS) — the measured
+// lever: one wave per SIMD left every LDS / MFMA latency exposed (dQ 140 -> 97 us, dK/dV 183 -> 123 us per layer).
+// EGOMI_ATTN_OCC (A/B switch): bit 0 / bit 1 clear = one block per CU, three stages, for dQ / dKdV
 static int attn_occ() {
     static int occ = -1;
-    if (occ < 0) { const char* e = getenv("EGOMI_ATTN_OCC"); occ = e ? atoi(e) : 1; }
+    if (occ < 0) { const char* e = getenv("EGOMI_ATTN_OCC"); occ = e ? atoi(e) : 3; }
     return occ;
 }
 static bool occ_dq2() { return attn_occ() & 1; }
@@ -630,8 +638,11 @@ extern "C" int egomi_attn_bwd(const egomi_attn_desc* d, egomi_stream_t stream) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q);
         EGOMI_LAUNCH(attn_bwd_dq_kernel<1>, grid, dim3(256), lds_q, s, a);
     }
-    const size_t lds_k = 3 * DKV_STAGE;
-    if (occ & 2) EGOMI_LAUNCH(attn_bwd_dkdv_kernel<2>, grid, dim3(256), lds_k, s, a);
+    const size_t lds_k = (occ & 2) ? 2 * DKV_STAGE + 128 * 256 : 3 * DKV_STAGE;
+    if (occ & 2) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkdv_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_k);
+        EGOMI_LAUNCH(attn_bwd_dkdv_kernel<2>, grid, dim3(256), lds_k, s, a);
+    }
     else EGOMI_LAUNCH(attn_bwd_dkdv_kernel<1>, grid, dim3(256), lds_k, s, a);
     return egomi_launch_status();
 }
