@@ -590,6 +590,13 @@ static int launch_8phase(const egomi_gemm_desc* d, FastArgs& g, hipStream_t s) {
         if (tp.rows > g.tiles_m) tp.rows = g.tiles_m;
         if (tp.s < 2 || tp.rows < 1) tp = {0, 1};
     }
+    if (tp.rows) {                                                    // slabs must fit the caller's scratch, slices must be non-empty
+        const long long rows_rel = d->M - (long long)(g.tiles_m - tp.rows) * 256;
+        const int nt = d->K / FT_BK;
+        if (tp.s > nt) tp.s = nt;
+        if (tp.s > 1) { const int per = (nt + tp.s - 1) / tp.s; tp.s = (nt + per - 1) / per; }
+        if (tp.s < 2 || rows_rel * d->N * 4 * tp.s > d->workspace_bytes) tp = {0, 1};
+    }
     g.full_tm = g.tiles_m - tp.rows; g.tail_s = tp.s; g.full_tiles = g.full_tm * g.tiles_n;
     const int nwg = g.full_tiles + tp.rows * g.tiles_n * tp.s;
     if (d->c_dtype == EGOMI_BF16) EGOMI_LAUNCH(gemm_nt_bf16_8phase_kernel<bf16_t>, dim3(nwg, 1), dim3(512), 0, s, g);

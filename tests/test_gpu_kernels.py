@@ -298,6 +298,47 @@ def test_gemm_tuned_nt_kernel(ops, M, N, K):
     assert _lib.lib().egomi_gemm_kernel_id(ctypes.byref(d)) == 1
 
 
+def _kernel_id(ops, A, W, C, M, N, K):
+    import ctypes
+    from egoscaler_amd import _lib
+    d = ops.GemmDesc()
+    d.A, d.B, d.C = A.data_ptr(), W.data_ptr(), C.data_ptr()
+    d.M, d.N, d.K, d.lda, d.ldb, d.ldc = M, N, K, K, K, C.stride(0)
+    d.ab_dtype, d.c_dtype, d.batch = 1, 1 if C.dtype == torch.bfloat16 else 0, 1
+    return _lib.lib().egomi_gemm_kernel_id(ctypes.byref(d))
+
+
+@pytest.mark.parametrize("M,N,K", [(2900, 4100, 2048), (3000, 3000, 2112), (5536, 4096, 4096)])
+def test_gemm_8phase_kernel(ops, M, N, K):
+    """256x256 8-phase kernel (egomi_gemm_kernel_id == 2): ragged M and N, odd K-tile count (2112 = 33 x 64), every
+    epilogue form, fp32 output, and the K-sliced tail rows (library plan, explicit plans rows*16+S, no workspace)."""
+    a, w = rnd(M, K, dtype=torch.bfloat16, seed=21), rnd(N, K, dtype=torch.bfloat16, seed=22, scale=0.05)
+    bias, res = rnd(N, dtype=torch.bfloat16, seed=23), rnd(M, N, dtype=torch.bfloat16, seed=24)
+    A, W, Bi, R = a.cuda(), w.cuda(), bias.cuda(), res.cuda()
+    ref = (A.float() @ W.float().t()).cpu()
+    out = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+    assert _kernel_id(ops, A, W, out, M, N, K) == 2
+    close(ops.mm(A, W, out=out), ref, 2e-2)
+    gen = ops.mm(A, W, force_generic=True)
+    assert float((out.float() - gen.float()).abs().max()) <= 2e-2 * float(ref.abs().max())
+    close(ops.mm(A, W, bias=Bi, act=ops.ACT_GELU, residual=R, alpha=0.5), F.gelu(0.5 * ref + bias.float()) + res.float(), 2e-2)
+    close(ops.mm(A, W, residual=R), ref + res.float(), 2e-2)                       # interior fast-path epilogue, residual
+    acc = R.clone()
+    close(ops.mm(A, W, out=acc, accumulate=True), ref + res.float(), 2e-2)          # ... and accumulate
+    f32 = torch.full((M, N), 2.0, dtype=torch.float32, device="cuda")
+    ops.mm(A, W, out=f32, accumulate=True)
+    close(f32, ref + 2.0, 1e-3)
+    ws = torch.empty(64 << 20, dtype=torch.float32, device="cuda")
+    tm = (M + 255) // 256
+    for rows, S in ((1, 2), (2, 4), (min(tm, 5), 3), (tm, 2)):                        # explicit tail plans, up to every row sliced
+        got = ops.mm(A, W, bias=Bi, residual=R, workspace=ws, split_k=rows * 16 + S)
+        close(got, ref + bias.float() + res.float(), 2e-2)
+    # deterministic: same plan, same bits
+    x1 = ops.mm(A, W, workspace=ws, split_k=2 * 16 + 2).clone()
+    x2 = ops.mm(A, W, workspace=ws, split_k=2 * 16 + 2)
+    assert torch.equal(x1, x2)
+
+
 def _ref_attention(qkv, B, S, H, hd, scale, causal, km):
     x = qkv.float().view(B, S, 3, H, hd)
     q, k, v = x[:, :, 0].transpose(1, 2), x[:, :, 1].transpose(1, 2), x[:, :, 2].transpose(1, 2)
