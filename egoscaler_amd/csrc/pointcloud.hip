@@ -473,3 +473,81 @@ extern "C" int egomi_knn_group(const float* pts, const float* center, int B, int
         return EGOMI_E_BADARG;
     return egomi_launch_status();
 }
+
+// =================================================================================================
+// N4  depth map -> dense cloud  (DepthAnything.get_depth after the network, depth.py:46-60)
+//   z      = nearest-neighbour resize of the prediction to the frame size.  Pillow's NEAREST walks each axis with a
+//            running double (xo = a/2; idx = (int)xo; xo += a, a = n_src/n_dst): the table kernel repeats that
+//            sequence (one thread per axis, <= a few thousand additions), because floor((x+0.5)*a) differs from it
+//   points = ((u-pp)/fx * z, (v-pp)/fy * z, z) in float64, every pixel, row-major;  colours = u8 / 255.0 in float64
+// HBM-bound: 7 B read (+ the small prediction, L2-resident) and 52 B written per pixel.
+// =================================================================================================
+__global__ void depth_tab_kernel(int h0, int w0, int H, int W, int32_t* tab) {   // tab = [W x-indices | H y-indices]
+    if (threadIdx.x > 1 || blockIdx.x) return;
+    const int n_src = threadIdx.x ? h0 : w0, n_dst = threadIdx.x ? H : W;
+    int32_t* t = tab + (threadIdx.x ? W : 0);
+    const double a = (double)n_src / (double)n_dst;
+    double xo = a * 0.5;
+    for (int x = 0; x < n_dst; ++x) {
+        int i = (int)xo;
+        t[x] = i < n_src - 1 ? i : n_src - 1;
+        xo += a;
+    }
+}
+
+__global__ __launch_bounds__(256) void depth_cloud_kernel(const float* pred, long long pred_stride, int w0, const uint8_t* rgb, int H, int W,
+                                                          double fx, double fy, double pp, const int32_t* tab,
+                                                          float* out_z, double* out_points, double* out_colors, long long total) {
+    // 256 consecutive pixels per block; the 3-double records (24-B stride per lane) are staged in LDS and leave as 16-B vectors
+    __shared__ __attribute__((aligned(16))) double sp[256 * 3], sc[256 * 3];
+    const long long i0 = (long long)blockIdx.x * 256;
+    const long long i = i0 + threadIdx.x;
+    const bool live = i < total;
+    if (live) {
+        const long long hw = (long long)H * W;
+        const int b = (int)(i / hw);
+        const int rem = (int)(i - (long long)b * hw);
+        const int v = rem / W, u = rem - v * W;
+        const float z = pred[(long long)b * pred_stride + (long long)tab[W + v] * w0 + tab[u]];
+        out_z[i] = z;
+        if (out_points) {
+            const double zd = (double)z;
+            const double xn = ((double)u - pp) / fx, yn = ((double)v - pp) / fy;     // depth.py:55-56
+            sp[threadIdx.x * 3 + 0] = xn * zd; sp[threadIdx.x * 3 + 1] = yn * zd; sp[threadIdx.x * 3 + 2] = zd;   // :57
+            const uint8_t* c = rgb + i * 3;
+            sc[threadIdx.x * 3 + 0] = (double)c[0] / 255.0; sc[threadIdx.x * 3 + 1] = (double)c[1] / 255.0;       // :58
+            sc[threadIdx.x * 3 + 2] = (double)c[2] / 255.0;
+        }
+    }
+    if (!out_points) return;
+    __syncthreads();
+    const long long left = total - i0;
+    const int npix = left < 256 ? (int)left : 256;
+    const int nvec = npix * 3 / 2;                                       // i0*3 doubles is 16-B aligned (i0 % 256 == 0)
+    typedef __attribute__((ext_vector_type(2))) double f64x2;
+    f64x2* gp = reinterpret_cast<f64x2*>(out_points + i0 * 3);
+    f64x2* gc = reinterpret_cast<f64x2*>(out_colors + i0 * 3);
+    for (int k = threadIdx.x; k < nvec; k += 256) {
+        gp[k] = *reinterpret_cast<const f64x2*>(sp + 2 * k);
+        gc[k] = *reinterpret_cast<const f64x2*>(sc + 2 * k);
+    }
+    if ((npix * 3) & 1) {                                                // odd tail double of the last block
+        if (threadIdx.x == 0) { out_points[i0 * 3 + npix * 3 - 1] = sp[npix * 3 - 1]; out_colors[i0 * 3 + npix * 3 - 1] = sc[npix * 3 - 1]; }
+    }
+}
+
+extern "C" int egomi_depth_to_cloud(const float* pred, int B, int h0, int w0, const uint8_t* rgb, int H, int W,
+                                    double fx, double fy, double pp, int32_t* tab_ws,
+                                    float* out_z, double* out_points, double* out_colors, egomi_stream_t stream) {
+    if (!pred || !tab_ws || !out_z) return EGOMI_E_BADARG;
+    if ((out_points == nullptr) != (out_colors == nullptr)) return EGOMI_E_BADARG;
+    if (out_points && !rgb) return EGOMI_E_BADARG;
+    if (B <= 0 || h0 <= 0 || w0 <= 0 || H <= 0 || W <= 0) return EGOMI_E_SHAPE;
+    if (out_points && !(fx > 0.0 && fy > 0.0 && pp > 0.0)) return EGOMI_E_BADARG;      // depth.py:53: the reference returns no cloud then
+    hipStream_t s = (hipStream_t)stream;
+    EGOMI_LAUNCH(depth_tab_kernel, dim3(1), dim3(64), 0, s, h0, w0, H, W, tab_ws);
+    const long long total = (long long)B * H * W;
+    EGOMI_LAUNCH(depth_cloud_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, pred, (long long)h0 * w0, w0, rgb, H, W,
+                 fx, fy, pp, tab_ws, out_z, out_points, out_colors, total);
+    return egomi_launch_status();
+}

@@ -61,6 +61,31 @@ def unproject_gather(rgb, depth, pp, fx, fy, d_thres=None, boxes=None, n_out=0):
     return pts, col, cnt
 
 
+def depth_to_cloud(pred, rgb, final_width, final_height, focal_len_x=0, focal_len_y=0, principal_point=0):
+    """N4 (depth.py:35-62): pred f32 [B,h0,w0] or [h0,w0], rgb u8 [B,H,W,3] or [H,W,3] ->
+    (z f32 [.., H, W], points f64 [.., H*W, 3] | None, colors f64 [.., H*W, 3] | None)."""
+    single = pred.dim() == 2
+    pred = _c(pred if not single else pred[None], torch.float32)
+    B, h0, w0 = pred.shape
+    H, W = int(final_height), int(final_width)
+    dev = pred.device
+    want = focal_len_x > 0 and focal_len_y > 0 and principal_point > 0            # depth.py:53
+    z = torch.empty(B, H, W, dtype=torch.float32, device=dev)
+    tab = torch.empty(W + H, dtype=torch.int32, device=dev)
+    pts = col = None
+    if want:
+        rgb = _c(rgb if rgb.dim() == 4 else rgb[None], torch.uint8)
+        if tuple(rgb.shape) != (B, H, W, 3):
+            raise ValueError(f"depth_to_cloud: rgb must be [{B},{H},{W},3], got {tuple(rgb.shape)}")
+        pts = torch.empty(B, H * W, 3, dtype=torch.float64, device=dev)
+        col = torch.empty(B, H * W, 3, dtype=torch.float64, device=dev)
+    call("egomi_depth_to_cloud", P(pred), c_i(B), c_i(h0), c_i(w0), P(rgb) if want else None, c_i(H), c_i(W),
+         c_d(float(focal_len_x)), c_d(float(focal_len_y)), c_d(float(principal_point)), P(tab), P(z), P(pts), P(col), S())
+    if single:
+        return z[0], (pts[0] if want else None), (col[0] if want else None)
+    return z, pts, col
+
+
 def pc_norm(points, colors):
     points, colors = _c(points, torch.float64), _c(colors, torch.float32)
     B, N, _ = points.shape

@@ -64,6 +64,17 @@ int egomi_unproject_gather(const uint8_t* rgb, const float* depth, const int32_t
                            int n_out, double* out_points, float* out_colors, int32_t* out_count,
                            void* workspace, size_t workspace_bytes, egomi_stream_t stream);
 
+/* N4  depth map -> dense cloud: everything DepthAnything.get_depth does after the network.
+ *     replaces  data/third_party/Depth-Anything-V2/metric_depth/depth.py:46-60 (get_depth) and :27-31 (get_only_depth),
+ *     called from data/train/7_get_object_trajectory.py:101-108
+ * pred f32 [B,h0,w0] network output, rgb u8 [B,H,W,3] (may be NULL when out_points is NULL), tab_ws i32 [W+H] scratch
+ * out_z f32 [B,H,W] = PIL Image.resize((W,H), NEAREST) of pred (Pillow's running-double index walk, bit-exact);
+ * out_points f64 [B,H*W,3] = ((u-pp)/fx*z, (v-pp)/fy*z, z), out_colors f64 [B,H*W,3] = rgb/255.0 — both or neither;
+ * the reference returns no cloud unless fx, fy, pp > 0 (depth.py:53): asking for one with such intrinsics is BADARG. */
+int egomi_depth_to_cloud(const float* pred, int B, int h0, int w0, const uint8_t* rgb, int H, int W,
+                         double fx, double fy, double pp, int32_t* tab_ws,
+                         float* out_z, double* out_points, double* out_colors, egomi_stream_t stream);
+
 /* A2  pc_norm: centre xyz on the centroid, divide by the largest radius, in float64; colours pass
  *     through.   replaces  models/pointllm/pointllm/data/utils.py:146-157
  * points f64 [B,N,3], colors f32 [B,N,3] -> out f32 [B,N,6] */

@@ -56,6 +56,20 @@ def _functions_from(path, names, glb):
     return [ns[n] for n in names]
 
 
+def _method_from(path, cls, name, glb):
+    """Compile one method of a class of a reference file in memory (decorators dropped) and return it as a function."""
+    tree = ast.parse(open(path).read(), filename=path)
+    for n in tree.body:
+        if isinstance(n, ast.ClassDef) and n.name == cls:
+            for f in n.body:
+                if isinstance(f, ast.FunctionDef) and f.name == name:
+                    f.decorator_list = []
+                    ns = dict(glb)
+                    exec(compile(ast.Module(body=[f], type_ignores=[]), path, "exec"), ns)
+                    return ns[name]
+    raise KeyError(f"{cls}.{name} not found in {path}")
+
+
 @contextlib.contextmanager
 def fixed_fps_start(start):
     orig = torch.randint
@@ -81,6 +95,36 @@ def set_mismatch(a, b):
 
 
 # -------------------------------------------------------------------------------------------------
+def gen_depth_cloud():
+    """N4: DepthAnything.get_depth (depth.py:35-62) with the network replaced by a synthetic prediction: the resize,
+    un-projection and colour conversion run as the reference wrote them (PIL + numpy)."""
+    import types
+    from PIL import Image
+    get_depth = _method_from(os.path.join(REF, "egoscaler/data/third_party/Depth-Anything-V2/metric_depth/depth.py"),
+                             "DepthAnything", "get_depth", {"np": np, "Image": Image})
+    get_only = _method_from(os.path.join(REF, "egoscaler/data/third_party/Depth-Anything-V2/metric_depth/depth.py"),
+                            "DepthAnything", "get_only_depth", {"np": np, "Image": Image})
+    rng = np.random.default_rng(11)
+    out = {}
+    for i, (h0, w0, H, W) in enumerate([(20, 28, 45, 37), (33, 33, 32, 32), (14, 50, 141, 97), (64, 48, 17, 23)]):
+        pred = (rng.random((h0, w0), dtype=np.float32) * 4 + 0.25).astype(np.float32)
+        rgb = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+        me = types.SimpleNamespace(model=types.SimpleNamespace(infer_image=lambda img, p=pred: p))
+        f, pp = 0.6 * W + 3.5, W // 2
+        z, pts, col = get_depth(me, Image.fromarray(rgb), W, H, focal_len_x=f, focal_len_y=f, principal_point=pp)
+        zo, po, co = OPC.depth_to_cloud(pred, rgb, W, H, f, f, pp)
+        assert z.dtype == np.float32 and pts.dtype == np.float64 and col.dtype == np.float64
+        assert np.array_equal(z, zo) and np.array_equal(pts, po) and np.array_equal(col, co), "oracle depth_to_cloud != reference"
+        z2 = get_only(me, Image.fromarray(rgb), W, H)
+        assert np.array_equal(z2, zo)
+        zn, pn, cn = get_depth(me, Image.fromarray(rgb), W, H)                 # intrinsics left at 0 -> no cloud
+        assert pn is None and cn is None and np.array_equal(zn, zo)
+        out[f"pred{i}"], out[f"rgb{i}"], out[f"f{i}"], out[f"pp{i}"] = pred, rgb, np.float64(f), np.int64(pp)
+        out[f"z{i}"], out[f"points{i}"], out[f"colors{i}"] = z, pts, col
+    np.savez_compressed(os.path.join(GOLD, "depth_cloud.npz"), **out)
+    print("depth_cloud: oracle == reference (4 size pairs), fixture written")
+
+
 def gen_pointcloud():
     (gpc,) = _functions_from(os.path.join(REF, "egoscaler/data/tools/pcm_tools.py"), ["get_points_colors"], {"np": np})
     H = W = 32
@@ -438,7 +482,7 @@ def gen_tiny_pc_unfrozen():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["pointcloud", "traj", "pointbert_full", "tiny_model", "tiny_pc_unfrozen"]
+    which = sys.argv[1:] or ["pointcloud", "depth_cloud", "traj", "pointbert_full", "tiny_model", "tiny_pc_unfrozen"]
     for w in which:
         globals()["gen_" + w]()
     sizes = {f: os.path.getsize(os.path.join(GOLD, f)) for f in sorted(os.listdir(GOLD))}

@@ -76,3 +76,37 @@ def clip_to_cloud(rgb_u8, depth, pp, f, d_thres, n_points):
     p, c = strided_subsample(p, c, n_points)
     pc = np.concatenate([p, c.astype(np.float64)], axis=1)
     return pc_norm(pc).astype(np.float32)
+
+
+# ---------------------------------------------------------------------------------------------
+# N4  depth map -> dense cloud     reference: data/third_party/Depth-Anything-V2/metric_depth/depth.py:35-62
+#     (DepthAnything.get_depth after model.infer_image; called from data/train/7_get_object_trajectory.py:101-108)
+# ---------------------------------------------------------------------------------------------
+def nearest_table(n_src: int, n_dst: int) -> np.ndarray:
+    """Source index of every destination index for PIL's Image.resize(..., Image.NEAREST) (depth.py:50).
+    Pillow (pinned here: 12.2.0; third-party, its C source is not in /root/reference) walks the row with a running
+    double:  xo = a*0.5; for x: idx = (int)xo; xo += a   with a = n_src / n_dst  — the repeated addition, not
+    floor((x+0.5)*a), is what its output follows (checked against Pillow itself in tests/test_oracle_golden.py)."""
+    a = float(n_src) / float(n_dst)
+    out = np.empty(n_dst, dtype=np.int64)
+    xo = a * 0.5
+    for x in range(n_dst):
+        out[x] = int(xo)
+        xo += a
+    return np.minimum(out, n_src - 1)
+
+
+def depth_to_cloud(pred: np.ndarray, rgb_u8: np.ndarray, final_width: int, final_height: int,
+                   focal_len_x=0, focal_len_y=0, principal_point=0):
+    """pred f32 [h0,w0] (network output), rgb u8 [final_height, final_width, 3] ->
+    (z f32 [H,W], points f64 [H*W,3] | None, colors f64 [H*W,3] | None), dtypes as numpy yields them at depth.py:51-58."""
+    ys, xs = nearest_table(pred.shape[0], final_height), nearest_table(pred.shape[1], final_width)
+    z = np.ascontiguousarray(pred[ys][:, xs])                                        # :50-51
+    if focal_len_x > 0 and focal_len_y > 0 and principal_point > 0:                  # :53
+        x, y = np.meshgrid(np.arange(final_width), np.arange(final_height))
+        x = (x - principal_point) / focal_len_x                                      # :55-56 (float64)
+        y = (y - principal_point) / focal_len_y
+        points = np.stack((np.multiply(x, z), np.multiply(y, z), z), axis=-1).reshape(-1, 3)   # :57
+        colors = rgb_u8.reshape(-1, 3) / 255.0                                       # :58 (uint8 / float -> float64)
+        return z, points, colors
+    return z, None, None

@@ -128,3 +128,84 @@ def test_bad_arguments_raise(ops):
         ops.fps(torch.zeros(1, 16, 3, device="cuda"), [99], 4)         # start out of range
     with pytest.raises(EgomiError):
         ops.fps(torch.zeros(1, 16, 3), [0], 4)                         # CPU tensor: no fallback
+
+
+# ------------------------------------------------------------------------------------------------ N4
+def test_depth_to_cloud_matches_reference_golden(ops, golden_dir):
+    """N4: tests/golden/depth_cloud.npz was recorded by running the reference's DepthAnything.get_depth (depth.py:35-62)
+    with a synthetic network output (oracle/gen_golden.py depth_cloud).  Bit-exact: resize indices, f64 points, f64 colours."""
+    g = np.load(os.path.join(golden_dir, "depth_cloud.npz"))
+    for i in range(4):
+        pred, rgb = g[f"pred{i}"], g[f"rgb{i}"]
+        H, W = rgb.shape[:2]
+        f, pp = float(g[f"f{i}"]), int(g[f"pp{i}"])
+        z, pts, col = ops.depth_to_cloud(torch.from_numpy(pred).cuda(), torch.from_numpy(rgb).cuda(), W, H, f, f, pp)
+        assert z.dtype == torch.float32 and pts.dtype == torch.float64 and col.dtype == torch.float64
+        assert np.array_equal(z.cpu().numpy(), g[f"z{i}"])
+        assert np.array_equal(pts.cpu().numpy(), g[f"points{i}"])
+        assert np.array_equal(col.cpu().numpy(), g[f"colors{i}"])
+        z2, p2, c2 = ops.depth_to_cloud(torch.from_numpy(pred).cuda(), None, W, H)          # get_only_depth / intrinsics 0
+        assert p2 is None and c2 is None and torch.equal(z2, z)
+
+
+@pytest.mark.parametrize("B,h0,w0,H,W", [(2, 518, 518, 1408, 1408), (1, 37, 91, 480, 640), (3, 64, 64, 64, 64), (1, 5, 7, 1, 1)])
+def test_depth_to_cloud_vs_oracle(ops, B, h0, w0, H, W):
+    """Full Aria frame size (1408^2 from a 518^2 prediction) and odd ratios against the oracle, plus size-independent
+    properties: z takes only values of pred, rows/columns repeat monotonically, the cloud's third column is z."""
+    from oracle import pointcloud as OPC
+    rng = np.random.default_rng(h0 * 1000 + W)
+    pred = (rng.random((B, h0, w0), dtype=np.float32) * 5 + 0.1).astype(np.float32)
+    rgb = rng.integers(0, 256, (B, H, W, 3), dtype=np.uint8)
+    f, pp = 610.5, max(1, W // 2)
+    z, pts, col = ops.depth_to_cloud(torch.from_numpy(pred).cuda(), torch.from_numpy(rgb).cuda(), W, H, f, f, pp)
+    for b in range(B if H * W < 500000 else 1):
+        zo, po, co = OPC.depth_to_cloud(pred[b], rgb[b], W, H, f, f, pp)
+        assert np.array_equal(z[b].cpu().numpy(), zo)
+        assert np.array_equal(pts[b].cpu().numpy(), po)
+        assert np.array_equal(col[b].cpu().numpy(), co)
+    zz = z.cpu().numpy()
+    assert np.array_equal(pts[..., 2].cpu().numpy().reshape(B, H, W), zz.astype(np.float64))
+    for b in range(B):
+        assert np.isin(zz[b], pred[b]).all()
+    ys, xs = OPC.nearest_table(h0, H), OPC.nearest_table(w0, W)
+    assert (np.diff(ys) >= 0).all() and (np.diff(xs) >= 0).all() and ys[-1] <= h0 - 1 and xs[-1] <= w0 - 1
+
+
+def test_depth_to_cloud_bad_arguments(ops):
+    from egoscaler_amd._lib import EgomiError
+    pred = torch.ones(4, 4, device="cuda")
+    with pytest.raises(ValueError):
+        ops.depth_to_cloud(pred, torch.zeros(3, 3, 3, dtype=torch.uint8, device="cuda"), 8, 8, 100.0, 100.0, 4)   # rgb size != final size
+    with pytest.raises(EgomiError):
+        ops.depth_to_cloud(torch.ones(4, 4), None, 8, 8)                                                      # CPU tensor: no fallback
+
+
+def test_depth_wrapper_mirror_and_static_scene_cloud(ops, golden_dir):
+    """The reference-shaped wrapper (depth.py:13-62) returns the golden arrays through its own method names, and the
+    device-side composition resize -> get_points_colors(boxes) equals the oracle's two steps."""
+    import types
+    from egoscaler_amd import depth as D
+    from oracle import pointcloud as OPC
+    g = np.load(os.path.join(golden_dir, "depth_cloud.npz"))
+    pred, rgb = g["pred0"], g["rgb0"]
+    H, W = rgb.shape[:2]
+    seen = {}
+
+    def infer_image(img):
+        seen["bgr"] = np.array_equal(img, rgb[:, :, ::-1])
+        return pred
+    da = D.DepthAnything(types.SimpleNamespace(infer_image=infer_image))
+    z, p, c = da.get_depth(rgb, W, H, focal_len_x=float(g["f0"]), focal_len_y=float(g["f0"]), principal_point=int(g["pp0"]))
+    assert seen["bgr"] and isinstance(z, np.ndarray)
+    assert np.array_equal(z, g["z0"]) and np.array_equal(p, g["points0"]) and np.array_equal(c, g["colors0"])
+    assert np.array_equal(da.get_only_depth(rgb, W, H), g["z0"])
+    z2, p2, c2 = da.get_depth(rgb, W, H)
+    assert p2 is None and c2 is None
+    bbox = [{"box": {"ymin": 4, "ymax": 19, "xmin": 2, "xmax": 30}}, {"box": {"ymin": 30, "ymax": 44, "xmin": 20, "xmax": 36}}]
+    f, pp = float(g["f0"]), int(g["pp0"])
+    pts, col = D.static_scene_cloud(torch.from_numpy(pred).cuda(), torch.from_numpy(rgb).cuda(), bbox, pp, f, f, d_thres=3.0)
+    zo, _, _ = OPC.depth_to_cloud(pred, rgb, W, H)
+    rgbd = np.concatenate([rgb, zo[..., None]], -1)
+    assert rgbd.dtype == np.float32
+    po, co, _ = OPC.unproject_frame(rgbd, W, H, pp, f, f, 3.0, [b["box"] for b in bbox])
+    assert np.array_equal(pts.cpu().numpy(), po) and np.array_equal(col.cpu().numpy(), co)

@@ -154,3 +154,26 @@ def test_splice_errors(golden_dir):
     txt = toks.clone()
     txt[1, (txt[1] >= dims.tok.point_patch) & (txt[1] <= dims.tok.point_end)] = 7
     assert OPL.splice_positions(txt, dims.tok, dims.pb.point_token_len)[1] == []
+
+
+def test_depth_to_cloud_oracle_vs_golden_and_pillow(golden_dir):
+    """N4 oracle: (1) equals the fixture recorded from the reference's get_depth (depth.py:35-62); (2) its index walk equals
+    Pillow's NEAREST resize itself on random size pairs (Pillow is the third-party library the reference calls, depth.py:50)."""
+    g = np.load(os.path.join(golden_dir, "depth_cloud.npz"))
+    for i in range(4):
+        rgb = g[f"rgb{i}"]
+        H, W = rgb.shape[:2]
+        z, p, c = OPC.depth_to_cloud(g[f"pred{i}"], rgb, W, H, float(g[f"f{i}"]), float(g[f"f{i}"]), int(g[f"pp{i}"]))
+        assert np.array_equal(z, g[f"z{i}"]) and np.array_equal(p, g[f"points{i}"]) and np.array_equal(c, g[f"colors{i}"])
+        assert p.dtype == np.float64 and c.dtype == np.float64 and z.dtype == np.float32
+        z0, p0, c0 = OPC.depth_to_cloud(g[f"pred{i}"], rgb, W, H)
+        assert p0 is None and c0 is None and np.array_equal(z0, z)
+    Image = pytest.importorskip("PIL.Image")
+    rng = np.random.default_rng(5)
+    for _ in range(60):
+        h0, w0 = (int(v) for v in rng.integers(2, 400, 2))
+        H, W = (int(v) for v in rng.integers(1, 900, 2))
+        pred = rng.standard_normal((h0, w0)).astype(np.float32)
+        ref = np.array(Image.fromarray(pred).resize((W, H), Image.NEAREST))
+        got = pred[OPC.nearest_table(h0, H)][:, OPC.nearest_table(w0, W)]
+        assert np.array_equal(ref, got), (h0, w0, H, W)

@@ -46,6 +46,14 @@ res["A1_unproject_subsample"] = {"ms": round(t * 1e3, 3), "alg_bytes": 7 * px + 
 t, (ptsd, cold, cntd) = timed(lambda: ops.unproject_gather(rgb[:1], depth[:1], pp, fx, fx, synth.DEPTH_THRESHOLD), reps=5)
 nv = int(cntd[0])
 res["A1_unproject_dense_1sample"] = {"ms": round(t * 1e3, 3), "alg_bytes": 7 * T * H * W + 36 * nv, "GBps": round((7 * T * H * W + 36 * nv) / t / 1e9, 1), "n_valid": nv}
+# N4: depth map -> dense cloud at the Aria frame size (518^2 prediction -> 1408^2 frame), 8 frames
+Bn, h0n, Hn = 8, 518, 1408
+predn = torch.rand(Bn, h0n, h0n, device="cuda") * 4 + 0.2
+rgbn = torch.randint(0, 256, (Bn, Hn, Hn, 3), dtype=torch.uint8, device="cuda")
+t, _ = timed(lambda: ops.depth_to_cloud(predn, rgbn, Hn, Hn, 610.0, 610.0, 704), reps=5)
+bn = Bn * Hn * Hn * 59 + Bn * h0n * h0n * 4
+res["N4_depth_to_cloud"] = {"ms": round(t * 1e3, 3), "alg_bytes": bn, "GBps": round(bn / t / 1e9, 1), "note": "includes the three torch.empty outputs"}
+del predn, rgbn
 t, pc = timed(lambda: ops.pc_norm(pts, col))
 res["A2_pc_norm"] = {"ms": round(t * 1e3, 3), "alg_bytes": B * N * (36 + 24), "GBps": round(B * N * 60 / t / 1e9, 1)}
 t, (idx, cen) = timed(lambda: ops.fps(pc, start, G))
