@@ -425,9 +425,39 @@ void gemm_nt_bf16_8phase_kernel(FastArgs g) {
     if (t < nt) P8_TILE(0, t)
     if (wr == 0) { P8_BAR }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // the tail's redundant DMAs drain before the block's LDS is released
+    __builtin_amdgcn_s_barrier();                                 // ... for every wave (unconditional: the epilogue below re-uses the stages per wave)
     const int row0 = g.full_tm * 256;
-    gemm_epilogue<TC, 8>(g, acc, m0 + wr * 128, n0 + wc * 64, lane,
-                         ksl > 1 ? g.ws + (long long)kz * (g.M - row0) * g.N : nullptr, row0);
+    const int mb = m0 + wr * 128, nb = n0 + wc * 64;
+    if (sizeof(TC) == 2 && ksl == 1 && !g.bias && !g.residual && !g.accumulate && g.act == 0 && g.alpha == 1.0f &&
+        nb + 64 <= g.N && (g.ldc & 7) == 0 && ((uintptr_t)g.C & 15) == 0) {              // wave-uniform
+        // plain bf16 store: the direct form writes 8-B pieces of 16 different rows per instruction (16 line transactions
+        // each; ~7 us per 256x256 tile with nothing to overlap it).  Each wave instead drops 64 rows x 64 columns at a time
+        // into a private LDS region (144-B pitch) and stores them back as 128-B row segments, 16 B per lane.
+        char* wb = reinterpret_cast<char*>(smem) + wave * (64 * 144);
+        bf16_t* C = reinterpret_cast<bf16_t*>(g.C);
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+            for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const f32x4 v = acc[j][4 * pass + ii];
+                    u32x2 o;
+                    o[0] = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+                    o[1] = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+                    *reinterpret_cast<u32x2*>(wb + (ii * 16 + (lane & 15)) * 144 + (j * 16 + (lane >> 4) * 4) * 2) = o;
+                }
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int r = it * 8 + (lane >> 3), ch = lane & 7;
+                const u32x4 v = *reinterpret_cast<const u32x4*>(wb + r * 144 + ch * 16);
+                const int m = mb + pass * 64 + r;
+                if (m < g.M) *reinterpret_cast<u32x4*>(C + (long long)m * g.ldc + nb + ch * 8) = v;
+            }
+        }
+        return;
+    }
+    gemm_epilogue<TC, 8>(g, acc, mb, nb, lane, ksl > 1 ? g.ws + (long long)kz * (g.M - row0) * g.N : nullptr, row0);
 #undef P8_TILE
 #undef P8_BAR
 #undef P8_MMA
