@@ -31,6 +31,7 @@ struct AttnArgs {
     long long ld_qkv, ld_o, ld_dqkv;
     float scale;
     int causal;
+    const float* rope_cos; const float* rope_sin;
 };
 
 __device__ __forceinline__ int sw_off(int row, int ch) {            // byte offset inside a [rows][256 B] tile
@@ -135,8 +136,13 @@ __device__ __forceinline__ void tile_dma_t(const bf16_t* base, long long ld, int
 // pitch: the 8-B writes of 32 rows spread over the banks) and stores it back as whole 256-B rows, 16 B per lane.
 #define AT_XPITCH 272
 #define AT_XBYTES (32 * AT_XPITCH)
+__device__ __forceinline__ void unpack8(const u32x4 v, float (&f)[8]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { f[2 * j] = __uint_as_float(v[j] << 16); f[2 * j + 1] = __uint_as_float(v[j] & 0xFFFF0000u); }
+}
 __device__ __forceinline__ void store_rows_via_lds(char* wbuf, const f32x16 (&acc)[4], const float mul, bf16_t* gbase, const long long ld,
-                                                   const int row0, const int nrows, const int lane) {
+                                                   const int row0, const int nrows, const int lane,
+                                                   const float* rcos = nullptr, const float* rsin = nullptr) {
     const int half = lane >> 5, rl = lane & 31;
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt)
@@ -150,7 +156,24 @@ __device__ __forceinline__ void store_rows_via_lds(char* wbuf, const f32x16 (&ac
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
         const int r = it * 4 + (lane >> 4), ch = lane & 15;
-        const u32x4 v = *reinterpret_cast<const u32x4*>(wbuf + r * AT_XPITCH + ch * 16);
+        u32x4 v = *reinterpret_cast<const u32x4*>(wbuf + r * AT_XPITCH + ch * 16);
+        if (rcos && row0 + r < nrows) {
+            // inverse rotation of the pair (d, d+64) on the bf16-rounded values, in egomi_rope's own rounding sequence
+            // (elementwise.hip rope_vec8_kernel, inverse = 1): lanes 0..7 of a row hold the first halves, 8..15 the second
+            const u32x4 w = *reinterpret_cast<const u32x4*>(wbuf + r * AT_XPITCH + (ch ^ 8) * 16);
+            float mine[8], other[8], c[8], sn[8], out[8];
+            unpack8(v, mine); unpack8(w, other);
+            load8<float>(rcos + (long long)(row0 + r) * (AT_HD / 2) + (ch & 7) * 8, c);
+            load8<float>(rsin + (long long)(row0 + r) * (AT_HD / 2) + (ch & 7) * 8, sn);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float cj = bf2f(f2bf(c[j])), sj = bf2f(f2bf(-sn[j]));
+                out[j] = ch < 8 ? bf2f(f2bf(mine[j] * cj)) + bf2f(f2bf(-other[j] * sj))          // a*c - b*s
+                                : bf2f(f2bf(mine[j] * cj)) + bf2f(f2bf(other[j] * sj));           // b*c + a*s
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = (uint32_t)f2bf(out[2 * j]) | ((uint32_t)f2bf(out[2 * j + 1]) << 16);
+        }
         if (row0 + r < nrows) *reinterpret_cast<u32x4*>(gbase + (long long)(row0 + r) * ld + ch * 8) = v;
     }
 }
@@ -440,7 +463,8 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_dq_kernel(AttnArgs a) {
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // the tail's redundant DMAs have landed ...
     __builtin_amdgcn_s_barrier();                                     // ... for every wave: the stages are free for the row exchange
-    store_rows_via_lds(smem + wave * AT_XBYTES, dq, a.scale, a.dq + row_base * a.ld_dqkv + h * AT_HD, a.ld_dqkv, q0 + wave * 32, a.S, lane);
+    store_rows_via_lds(smem + wave * AT_XBYTES, dq, a.scale, a.dq + row_base * a.ld_dqkv + h * AT_HD, a.ld_dqkv, q0 + wave * 32, a.S, lane,
+                       a.rope_cos, a.rope_sin);
 }
 
 // =================================================================================================
@@ -567,7 +591,8 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_dkdv_kernel(AttnArgs a) {
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    store_rows_via_lds(smem + wave * AT_XBYTES, dk, a.scale, a.dk + row_base * a.ld_dqkv + h * AT_HD, a.ld_dqkv, kb0 + wave * 32, a.S, lane);
+    store_rows_via_lds(smem + wave * AT_XBYTES, dk, a.scale, a.dk + row_base * a.ld_dqkv + h * AT_HD, a.ld_dqkv, kb0 + wave * 32, a.S, lane,
+                       a.rope_cos, a.rope_sin);
     store_rows_via_lds(smem + wave * AT_XBYTES, dv, 1.0f, a.dv + row_base * a.ld_dqkv + h * AT_HD, a.ld_dqkv, kb0 + wave * 32, a.S, lane);
 }
 
@@ -597,6 +622,7 @@ static AttnArgs attn_args(const egomi_attn_desc* d) {
     a.dout = (const bf16_t*)d->dout; a.delta = d->delta; a.dq = (bf16_t*)d->dq; a.dk = (bf16_t*)d->dk; a.dv = (bf16_t*)d->dv;
     a.key_mask = d->key_mask; a.B = d->B; a.H = d->H; a.S = d->S;
     a.ld_qkv = d->ld_qkv; a.ld_o = d->ld_o; a.ld_dqkv = d->ld_dqkv; a.scale = d->scale; a.causal = d->causal;
+    a.rope_cos = d->rope_cos; a.rope_sin = d->rope_sin;
     return a;
 }
 
@@ -624,6 +650,8 @@ extern "C" int egomi_attn_bwd(const egomi_attn_desc* d, egomi_stream_t stream) {
     if (d->ld_o % 8 || d->ld_dqkv % 8 || d->ld_o < AT_HD * d->H || d->ld_dqkv < AT_HD * d->H) return EGOMI_E_SHAPE;
     if (((uintptr_t)d->dout & 15) || (((uintptr_t)d->dq | (uintptr_t)d->dk | (uintptr_t)d->dv) & 15) || ((uintptr_t)d->o & 15)) return EGOMI_E_SHAPE;
     if (d->S > AT_MAXS) return EGOMI_E_UNSUPPORTED;
+    if ((d->rope_cos == nullptr) != (d->rope_sin == nullptr)) return EGOMI_E_BADARG;
+    if (d->rope_cos && (((uintptr_t)d->rope_cos | (uintptr_t)d->rope_sin) & 15)) return EGOMI_E_SHAPE;
     AttnArgs a = attn_args(d);
     hipStream_t s = (hipStream_t)stream;
     const long long items = (long long)d->B * d->S * d->H;

@@ -444,11 +444,12 @@ class Engine:
             self._wgrad(p + "self_attn.o_proj.weight", d_mid, lc["ao"])
             dqkv = ws.get("dqkv", (M, 3 * d), T)
             if lc["lse"] is not None:
+                # dq, dk leave the kernels already rotated back (the inverse RoPE pass is fused into their epilogues)
                 ops.attn_bwd(qkv, lc["ao"], lc["lse"], d_ao, dqkv, ws.get("att_delta", (B, H, S), torch.float32), B, S, H, hd, scale,
-                             causal=True, key_mask=ctx["key_mask"])
+                             causal=True, key_mask=ctx["key_mask"], rope=(self.cos, self.sin))
             else:
                 self._attention_bwd(qkv, lc["P"], d_ao, dqkv, B, S, H, hd, scale)
-            ops.rope_(dqkv, self.cos, self.sin, M, S, 0, 2 * H, hd, 3 * d, inverse=True)
+                ops.rope_(dqkv, self.cos, self.sin, M, S, 0, 2 * H, hd, 3 * d, inverse=True)
             if self.prepared and l in self.wqkvT:
                 d_h = ops.mm(dqkv, self.wqkvT[l], out=ws.get("d_h", (M, d), T))
             else:

@@ -385,7 +385,7 @@ class AttnDesc(ctypes.Structure):
                 ("dout", c_p), ("delta", c_p), ("dq", c_p), ("dk", c_p), ("dv", c_p), ("key_mask", c_p),
                 ("B", c_i), ("H", c_i), ("S", c_i), ("head_dim", c_i),
                 ("ld_qkv", c_i64), ("ld_o", c_i64), ("ld_dqkv", c_i64),
-                ("scale", c_f), ("causal", c_i), ("dtype", c_i)]
+                ("scale", c_f), ("causal", c_i), ("dtype", c_i), ("rope_cos", c_p), ("rope_sin", c_p)]
 
 
 def _attn_desc(qkv, B, Sq, H, hd, scale, causal, key_mask):
@@ -407,9 +407,16 @@ def attn_fwd(qkv, B, Sq, H, hd, scale, out, lse, causal=True, key_mask=None):
     return out
 
 
-def attn_bwd(qkv, out, lse, dout, dqkv, delta, B, Sq, H, hd, scale, causal=True, key_mask=None):
-    """dq|dk|dv written into the column blocks of dqkv [B*S, 3*H*hd]; delta fp32 [B,H,S] is scratch."""
+def attn_bwd(qkv, out, lse, dout, dqkv, delta, B, Sq, H, hd, scale, causal=True, key_mask=None, rope=None):
+    """dq|dk|dv written into the column blocks of dqkv [B*S, 3*H*hd]; delta fp32 [B,H,S] is scratch.
+    rope=(cos, sin) fp32 [>=S, hd/2]: dq and dk come out rotated back (== rope_(dqkv, inverse=True) afterwards)."""
     d = _attn_desc(qkv, B, Sq, H, hd, scale, causal, key_mask)
+    if rope is not None:
+        cos, sin = rope
+        if cos.dtype != torch.float32 or sin.dtype != torch.float32 or cos.shape[0] < Sq or cos.shape[1] != hd // 2 \
+                or not cos.is_contiguous() or not sin.is_contiguous():
+            raise ValueError("attn_bwd: rope tables must be contiguous fp32 [>=S, head_dim/2]")
+        d.rope_cos, d.rope_sin = cos.data_ptr(), sin.data_ptr()
     dm = H * hd
     d.o, d.lse, d.ld_o = out.data_ptr(), lse.data_ptr(), out.stride(0)
     if dout.stride(0) != out.stride(0):

@@ -134,7 +134,7 @@ int egomi_gemm(const egomi_gemm_desc* desc, egomi_stream_t stream);
 int egomi_gemm_kernel_id(const egomi_gemm_desc* desc);
 
 /* ------------------------------------------------------------------------------------------------
- * Fused attention (bf16, head_dim 128): softmax(scale * Q.K^T + mask).V without materialising the
+ * Fused attention (bf16, head_dim 128; forward also head_dim 64): softmax(scale * Q.K^T + mask).V without materialising the
  * [S,S] scores.  replaces HF eager_attention_forward, transformers/models/llama/modeling_llama.py:
  * 191-214, and its autograd backward (A11).
  * q/k/v: rows = b*S + s, row stride ld_qkv elements, head h at column h*head_dim (q, k, v may be
@@ -153,6 +153,11 @@ typedef struct egomi_attn_desc {
     float scale;
     int causal;
     int dtype;
+    /* optional, backward only: q and k were rotated (HF apply_rotary_pos_emb, modeling_llama.py:139-167) before the
+     * attention; when both tables are given (fp32 [>= S, head_dim/2], row = position s), egomi_attn_bwd writes dq and dk
+     * already rotated back (what egomi_rope(..., inverse=1) on the bf16 dq/dk would give, bit for bit), so the caller
+     * drops that pass.  NULL = plain dq/dk. */
+    const float* rope_cos; const float* rope_sin;
 } egomi_attn_desc;
 int egomi_attn_fwd(const egomi_attn_desc* desc, egomi_stream_t stream);
 int egomi_attn_bwd(const egomi_attn_desc* desc, egomi_stream_t stream);

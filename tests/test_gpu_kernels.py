@@ -298,6 +298,29 @@ def test_gemm_tuned_nt_kernel(ops, M, N, K):
     assert _lib.lib().egomi_gemm_kernel_id(ctypes.byref(d)) == 1
 
 
+def test_fused_attention_backward_with_inverse_rope(ops):
+    """egomi_attn_bwd with rope tables: dq and dk equal the plain kernel's output followed by egomi_rope(inverse=1), bit for bit;
+    dv is untouched."""
+    B, S, H, hd = 2, 200, 3, 128
+    d = H * hd
+    qkv = rnd(B * S, 3 * d, dtype=torch.bfloat16, seed=5).cuda()
+    dout = rnd(B * S, d, dtype=torch.bfloat16, seed=6, scale=0.1).cuda()
+    out = torch.zeros(B * S, d, dtype=torch.bfloat16, device="cuda")
+    lse = torch.zeros(B, H, S, dtype=torch.float32, device="cuda")
+    ops.attn_fwd(qkv, B, S, H, hd, hd ** -0.5, out, lse, causal=True)
+    delta = torch.empty_like(lse)
+    cos, sin = ops.rope_tables(256, hd, 10000.0)
+    cos, sin = cos.cuda(), sin.cuda()
+    plain = torch.zeros_like(qkv)
+    ops.attn_bwd(qkv, out, lse, dout, plain, delta, B, S, H, hd, hd ** -0.5, causal=True)
+    ops.rope_(plain, cos, sin, B * S, S, 0, 2 * H, hd, 3 * d, inverse=True)
+    fused = torch.zeros_like(qkv)
+    ops.attn_bwd(qkv, out, lse, dout, fused, delta, B, S, H, hd, hd ** -0.5, causal=True, rope=(cos, sin))
+    assert torch.equal(fused, plain)
+    with pytest.raises(ValueError):
+        ops.attn_bwd(qkv, out, lse, dout, fused, delta, B, S, H, hd, hd ** -0.5, causal=True, rope=(cos[:100], sin[:100]))
+
+
 def _kernel_id(ops, A, W, C, M, N, K):
     import ctypes
     from egoscaler_amd import _lib
