@@ -1,18 +1,20 @@
-// Tuned bf16 "NT" GEMM for the LLaMA-sized projections:  C[M,N] = A[M,K] . B[N,K]^T  (+ epilogue)
-//   * both operands K-contiguous (activation x nn.Linear weight; dgrad uses pre-transposed weights,
-//     wgrad uses transposed activations, so every big product of the path has this form)
-//   * BM x BN x 64 tile, one wave per 64x64 sub-tile (v_mfma_f32_16x16x32_bf16, fp32 accumulate):
-//       256x128 (8 waves, 48 KB LDS, 2 blocks/CU) for large M — rocprofv3 PMC showed the 128x128 tile
-//       parked ~49 % of wave time on vmcnt/barrier with zero LDS bank conflicts, i.e. bound by the
-//       per-CU LDS-DMA fill rate (~70 GB/s/CU from L2); the wider tile moves 25 % fewer bytes per flop
-//       128x128 (4 waves, 32 KB LDS, 4 blocks/CU) otherwise
+// Tuned bf16 "NT" GEMMs for the LLaMA-sized projections:  C[M,N] = A[M,K] . B[N,K]^T  (+ epilogue)
+//   both operands K-contiguous (activation x nn.Linear weight; dgrad uses pre-transposed weights, wgrad uses
+//   transposed activations, so every big product of the path has this form).  Two kernels:
+//   (1) gemm_nt_bf16_8phase_kernel — 256x256x64 tile, 8 waves, LDS-DMA kept in flight across raw barriers, two wave
+//       groups one barrier apart (see its header below).  >= 128 tiles and K >= 2048: every large product of the step.
+//       Ragged last round: K-sliced tail rows (plan_tail) or nothing; plain bf16 tiles leave through LDS as row segments.
+//   (2) gemm_nt_bf16_kernel<BM,BN> — 128x128 (4 waves, 32 KB LDS, 4 blocks/CU) or 256x128 (8 waves, 48 KB), one wave
+//       per 64x64 sub-tile, two barriers per K-step (~1.0 PFLOP/s ceiling).  Small / short-K products and the
+//       M <= 512 split-K decode path.
+//   Common to both:
 //   * global -> LDS by LDS-DMA (global_load_lds_dwordx4): no staging VGPRs, no ds_write
 //   * LDS image linear [row][64 k] (128-B rows); bank conflicts removed by an XOR swizzle applied to
 //     the per-lane SOURCE address and to the fragment read (chunk ^= (row>>1)&7): the 16 rows of a
 //     fragment land on 16 distinct 16-B slots of the 256-B bank row (cdna_hip_programming.md rule 21);
 //     measured SQ_LDS_BANK_CONFLICT = 0
 //   * operands are fed swapped (weights as the MFMA A operand) so each lane's 4 accumulators are 4
-//     consecutive output columns -> 8-B / 16-B epilogue stores
+//     consecutive output columns
 //   * rows beyond M / N are clamped on load and masked on store; K % 64 == 0
 //   * XCD-aware block order: each XCD walks a contiguous strip of tiles, grouped 8 M-tiles deep (T1)
 #include "common.h"
@@ -168,13 +170,14 @@ __device__ __forceinline__ void gemm_epilogue(const FastArgs& g, const f32x4 (&a
     }
 }
 
-template <typename TC, int BM, int BN, int DB, int MT = 4>
-__global__ __launch_bounds__((BM / (16 * MT)) * (BN / 64) * 64, (DB || MT == 8) ? 2 : ((BM * BN == 256 * 128) ? 4 : 3))
+template <typename TC, int BM, int BN>
+__global__ __launch_bounds__((BM / 64) * (BN / 64) * 64, (BM * BN == 256 * 128) ? 4 : 3)
 void gemm_nt_bf16_kernel(FastArgs g) {
-    constexpr int WN = BN / 64, NW = (BM / (16 * MT)) * WN;
+    constexpr int MT = 4;                                                // 16-row MFMA tiles per wave in M (64 x 64 per wave)
+    constexpr int WN = BN / 64, NW = (BM / 64) * WN;
     constexpr int A_PW = BM / 8 / NW, B_PW = BN / 8 / NW;               // 1-KiB DMA pieces (8 rows x 128 B) per wave
     constexpr int STAGE = (BM + BN) * FT_BK;
-    __shared__ __attribute__((aligned(16))) bf16_t smem[(DB ? 2 : 1) * STAGE];   // one array (cdna guide: second-__shared__ trap)
+    __shared__ __attribute__((aligned(16))) bf16_t smem[STAGE];
     bf16_t* sA = smem;
     bf16_t* sB = smem + BM * FT_BK;
     const int lane = threadIdx.x & 63;
@@ -235,35 +238,11 @@ void gemm_nt_bf16_kernel(FastArgs g) {
         t_begin = blockIdx.y * per;
         nt = t_begin + per < nt ? t_begin + per : nt;
     }
-    if (DB) {
-        // two LDS stages: the DMA of tile t+1 is in flight while tile t is multiplied (counted vmcnt + raw
-        // s_barrier, cdna_hip_programming.md "Pipelining across barriers")
-#pragma unroll
-        for (int i = 0; i < A_PW; ++i) glds16(srcA[i] + t_begin * FT_BK, sA + (t_begin & 1) * STAGE + (wave * A_PW + i) * 8 * FT_BK);
-#pragma unroll
-        for (int i = 0; i < B_PW; ++i) glds16(srcB[i] + t_begin * FT_BK, sB + (t_begin & 1) * STAGE + (wave * B_PW + i) * 8 * FT_BK);
-    }
     for (int t = t_begin; t < nt; ++t) {
         const int k0 = t * FT_BK;
         const bf16_t* cA = sA;
         const bf16_t* cB = sB;
-        if (DB) {
-            cA = sA + (t & 1) * STAGE;
-            cB = sB + (t & 1) * STAGE;
-            if (t + 1 < nt) {
-                bf16_t* nA = sA + ((t + 1) & 1) * STAGE;
-                bf16_t* nB = sB + ((t + 1) & 1) * STAGE;
-#pragma unroll
-                for (int i = 0; i < A_PW; ++i) glds16(srcA[i] + k0 + FT_BK, nA + (wave * A_PW + i) * 8 * FT_BK);
-#pragma unroll
-                for (int i = 0; i < B_PW; ++i) glds16(srcB[i] + k0 + FT_BK, nB + (wave * B_PW + i) * 8 * FT_BK);
-                if (A_PW + B_PW == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-            } else {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-            __builtin_amdgcn_s_barrier();
-        } else {
+        {
 #pragma unroll
             for (int i = 0; i < A_PW; ++i) glds16(srcA[i] + k0, sA + (wave * A_PW + i) * 8 * FT_BK);
 #pragma unroll
@@ -283,12 +262,7 @@ void gemm_nt_bf16_kernel(FastArgs g) {
                 for (int i = 0; i < MT; ++i)
                     acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[j][i], 0, 0, 0);
         }
-        if (DB) {
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();                           // stage (t&1) may be refilled by the DMA of tile t+2
-        } else {
-            __syncthreads();                                        // tile consumed before it is overwritten
-        }
+        __syncthreads();                                            // tile consumed before it is overwritten
     }
 
     gemm_epilogue<TC, MT>(g, acc, m0 + wm, n0 + wn, lane, g.splitk > 1 ? g.ws + (long long)blockIdx.y * g.M * g.N : nullptr, 0);
@@ -512,11 +486,11 @@ static bool fast_applicable(const egomi_gemm_desc* d) {
     return true;
 }
 
-// tile choice: 2 = 256x128, 1 = 128x128.  EGOMI_GEMM_TILE=1|2 overrides (A/B experiments).
+// tile choice: 8 = 256x256 8-phase kernel, 2 = 256x128, 1 = 128x128.  EGOMI_GEMM_TILE=1|2|8 overrides (A/B runs).
 static int tile_choice(const egomi_gemm_desc* d) {
     static int forced = -1;
     if (forced < 0) { const char* e = getenv("EGOMI_GEMM_TILE"); forced = e ? atoi(e) : 0; }
-    if (forced >= 1 && forced <= 8) return forced;
+    if (forced == 1 || forced == 2 || forced == 8) return forced;
     // measured (tools/gemm_bench.py, M=5536): 256x128 wins only where N is wide enough to keep every CU at
     // 2 resident blocks to the end (N=11008: 1168 vs 1084 TFLOP/s); at N=4096 its 704 tiles quantise worse
     // than 1408 tiles of 128x128 (952 vs 1010)
@@ -533,11 +507,11 @@ extern "C" int egomi_gemm_kernel_id(const egomi_gemm_desc* d) {
     return tile_choice(d) == 8 ? 2 : 1;
 }
 
-template <int BM, int BN, int DB, int MT = 4>
+template <int BM, int BN>
 static int launch_fast(const egomi_gemm_desc* d, FastArgs& g, hipStream_t s) {
     g.tiles_m = (d->M + BM - 1) / BM; g.tiles_n = (d->N + BN - 1) / BN;
     const int nwg = g.tiles_m * g.tiles_n;
-    constexpr int threads = (BM / (16 * MT)) * (BN / 64) * 64;
+    constexpr int threads = (BM / 64) * (BN / 64) * 64;
     // skinny products (decode, M <= 512): too few tiles to fill 256 CUs and each block is DMA-latency bound,
     // so the K range is split over blockIdx.y into fp32 slabs (caller-provided workspace) and combined
     g.splitk = 1; g.ws = (float*)d->workspace;
@@ -552,8 +526,8 @@ static int launch_fast(const egomi_gemm_desc* d, FastArgs& g, hipStream_t s) {
         if (sk > 1) { const int per = (nt + sk - 1) / sk; sk = (nt + per - 1) / per; }     // no empty slices
         if (sk > 1) g.splitk = sk;
     }
-    if (d->c_dtype == EGOMI_BF16) EGOMI_LAUNCH((gemm_nt_bf16_kernel<bf16_t, BM, BN, DB, MT>), dim3(nwg, g.splitk), dim3(threads), 0, s, g);
-    else if (d->c_dtype == EGOMI_F32) EGOMI_LAUNCH((gemm_nt_bf16_kernel<float, BM, BN, DB, MT>), dim3(nwg, g.splitk), dim3(threads), 0, s, g);
+    if (d->c_dtype == EGOMI_BF16) EGOMI_LAUNCH((gemm_nt_bf16_kernel<bf16_t, BM, BN>), dim3(nwg, g.splitk), dim3(threads), 0, s, g);
+    else if (d->c_dtype == EGOMI_F32) EGOMI_LAUNCH((gemm_nt_bf16_kernel<float, BM, BN>), dim3(nwg, g.splitk), dim3(threads), 0, s, g);
     else return EGOMI_E_UNSUPPORTED;
     if (g.splitk > 1) {
         const long long total = (long long)d->M * ((d->N + 3) / 4);
@@ -656,10 +630,5 @@ int egomi_gemm_fast_try(const egomi_gemm_desc* d, hipStream_t s) {
     g.alpha = d->alpha; g.accumulate = d->accumulate; g.act = d->act;
     const int tc = tile_choice(d);
     if (tc == 8 && (long long)d->M * d->lda < (1ll << 31) && (long long)d->N * d->ldb < (1ll << 31)) return launch_8phase(d, g, s);
-    if (tc == 3) return launch_fast<128, 128, 1>(d, g, s);          // experiment: double-buffered 128x128
-    if (tc == 4) return launch_fast<256, 256, 1, 8>(d, g, s);       // experiment: 256x256, 8 waves of 128x64, double-buffered (128 KB LDS)
-    if (tc == 6) return launch_fast<128, 128, 0, 8>(d, g, s);       // experiment: 128x128 as 2 waves of 128x64 (LDS reads / MFMA = 0.75)
-    if (tc == 7) return launch_fast<256, 128, 0, 8>(d, g, s);       // experiment: 256x128 as 4 waves of 128x64
-    if (tc == 5) return launch_fast<256, 64, 0>(d, g, s);           // skinny M (decode): all 256 rows x 64 columns per block, split-K
-    return tc == 2 ? launch_fast<256, 128, 0>(d, g, s) : launch_fast<128, 128, 0>(d, g, s);
+    return tc == 2 ? launch_fast<256, 128>(d, g, s) : launch_fast<128, 128>(d, g, s);
 }
