@@ -85,11 +85,11 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const T* x, const T* w
 // dx = rstd * (g - x_hat * mean(g * x_hat)),  g = w * dy;  dw[c] += sum_rows dy * x_hat.
 // grid = min(rows, 1024) blocks, each loops over rows; dw partials kept in registers, one atomic
 // per column per block at the end.
-template <typename T>
+template <typename T, int MAXV>
 __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const T* dy, const T* x, const T* w, const float* rstd, T* dx, const T* dx_add,
                                                           float* dw, int rows, int cols) {
     __shared__ float red[16];
-    constexpr int MAXV = 4;                              // cols <= 256*8*4 = 8192
+    // MAXV = ceil(cols / 2048) chunks of 8 columns per thread (cols <= 8192)
     float dwp[MAXV][8];
 #pragma unroll
     for (int i = 0; i < MAXV; ++i)
@@ -98,6 +98,7 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const T* dy, const T* 
     for (long long row = blockIdx.x; row < rows; row += gridDim.x) {
         const float rs = rstd[row];
         float dot = 0.f;
+        float gw[MAXV][8], xh[MAXV][8], ad[MAXV][8];         // g*w, x*rstd and the residual gradient stay in registers between the passes
 #pragma unroll
         for (int i = 0; i < MAXV; ++i) {
             const int c = (threadIdx.x + i * 256) * 8;
@@ -106,8 +107,14 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const T* dy, const T* 
                 load8<T>(dy + row * cols + c, g);
                 load8<T>(x + row * cols + c, xv);
                 load8<T>(w + c, ww);
+                if (dx_add) load8<T>(dx_add + row * cols + c, ad[i]);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) dot += g[j] * ww[j] * xv[j] * rs;
+                for (int j = 0; j < 8; ++j) {
+                    dot += g[j] * ww[j] * xv[j] * rs;
+                    gw[i][j] = g[j] * ww[j];
+                    xh[i][j] = xv[j] * rs;
+                    dwp[i][j] += g[j] * xh[i][j];
+                }
             }
         }
         const float mean = block_sum(dot, red) / cols;
@@ -115,17 +122,9 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const T* dy, const T* 
         for (int i = 0; i < MAXV; ++i) {
             const int c = (threadIdx.x + i * 256) * 8;
             if (c < cols) {
-                float g[8], xv[8], ww[8], o[8], ad[8];
-                load8<T>(dy + row * cols + c, g);
-                load8<T>(x + row * cols + c, xv);
-                load8<T>(w + c, ww);
-                if (dx_add) load8<T>(dx_add + row * cols + c, ad);
+                float o[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float xh = xv[j] * rs;
-                    o[j] = rs * (g[j] * ww[j] - xh * mean) + (dx_add ? ad[j] : 0.f);
-                    dwp[i][j] += g[j] * xh;
-                }
+                for (int j = 0; j < 8; ++j) o[j] = rs * (gw[i][j] - xh[i][j] * mean) + (dx_add ? ad[i][j] : 0.f);
                 store8<T>(dx + row * cols + c, o);
             }
         }
@@ -155,9 +154,19 @@ extern "C" int egomi_rmsnorm_bwd(const void* dy, const void* x, const void* w, c
     if (!dy || !x || !w || !rstd || !dx) return EGOMI_E_BADARG;
     if (rows <= 0 || cols <= 0 || cols % 8) return EGOMI_E_SHAPE;
     if (cols > 8192) return EGOMI_E_UNSUPPORTED;
-    const int grid = rows < 1024 ? rows : 1024;
-    EGOMI_DISPATCH_DTYPE(dtype, EGOMI_LAUNCH(rmsnorm_bwd_kernel<T>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
-                                                   (const T*)dy, (const T*)x, (const T*)w, rstd, (T*)dx, (const T*)dx_add, dw, rows, cols));
+    // dw: partials live in registers across the rows of a block (one atomic per column and block) -> few blocks;
+    // without dw (frozen norm weights) one row per block keeps every CU's memory pipe full
+    const int grid = dw ? (rows < 1024 ? rows : 1024) : rows;
+    if (cols <= 2048) {
+        EGOMI_DISPATCH_DTYPE(dtype, EGOMI_LAUNCH((rmsnorm_bwd_kernel<T, 1>), dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                                                       (const T*)dy, (const T*)x, (const T*)w, rstd, (T*)dx, (const T*)dx_add, dw, rows, cols));
+    } else if (cols <= 4096) {
+        EGOMI_DISPATCH_DTYPE(dtype, EGOMI_LAUNCH((rmsnorm_bwd_kernel<T, 2>), dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                                                       (const T*)dy, (const T*)x, (const T*)w, rstd, (T*)dx, (const T*)dx_add, dw, rows, cols));
+    } else {
+        EGOMI_DISPATCH_DTYPE(dtype, EGOMI_LAUNCH((rmsnorm_bwd_kernel<T, 4>), dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                                                       (const T*)dy, (const T*)x, (const T*)w, rstd, (T*)dx, (const T*)dx_add, dw, rows, cols));
+    }
     return egomi_launch_status();
 }
 
