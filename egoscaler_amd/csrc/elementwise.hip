@@ -83,18 +83,11 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const T* x, const T* w
 }
 
 // dx = rstd * (g - x_hat * mean(g * x_hat)),  g = w * dy;  dw[c] += sum_rows dy * x_hat.
-// grid = min(rows, 1024) blocks, each loops over rows; dw partials kept in registers, one atomic
-// per column per block at the end.
+// one row per block (grid-stride kept for generality); the weight gradient is rmsnorm_dw_kernel's job.
 template <typename T, int MAXV>
-__global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const T* dy, const T* x, const T* w, const float* rstd, T* dx, const T* dx_add,
-                                                          float* dw, int rows, int cols) {
+__global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const T* dy, const T* x, const T* w, const float* rstd, T* dx, const T* dx_add, int rows, int cols) {
     __shared__ float red[16];
     // MAXV = ceil(cols / 2048) chunks of 8 columns per thread (cols <= 8192)
-    float dwp[MAXV][8];
-#pragma unroll
-    for (int i = 0; i < MAXV; ++i)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) dwp[i][j] = 0.f;
     for (long long row = blockIdx.x; row < rows; row += gridDim.x) {
         const float rs = rstd[row];
         float dot = 0.f;
@@ -113,7 +106,6 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const T* dy, const T* 
                     dot += g[j] * ww[j] * xv[j] * rs;
                     gw[i][j] = g[j] * ww[j];
                     xh[i][j] = xv[j] * rs;
-                    dwp[i][j] += g[j] * xh[i][j];
                 }
             }
         }
@@ -129,14 +121,36 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const T* dy, const T* 
             }
         }
     }
-    if (dw) {
+}
+
+// dw[c] += sum_r dy[r,c] * (x[r,c] * rstd[r]) as its own pass: 64 columns per block (8 lanes x 8 columns, 32 rows in flight),
+// rows split over gridDim.y, one atomic per column and block.  The in-kernel form (partials in registers, 1024 blocks x cols
+// atomics onto cols addresses) took 264 us at 5536 x 4096; this pass re-reads dy and x (L2/Infinity-Cache warm) in ~20 us.
+template <typename T>
+__global__ __launch_bounds__(256) void rmsnorm_dw_kernel(const T* dy, const T* x, const float* rstd, float* dw, int rows, int cols) {
+    __shared__ float red[32][65];
+    const int cl = threadIdx.x & 7, rl = threadIdx.x >> 3;
+    const int c = blockIdx.x * 64 + cl * 8;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (c < cols) {
+        for (long long r = (long long)blockIdx.y * 32 + rl; r < rows; r += 32ll * gridDim.y) {
+            float g[8], xv[8];
+            load8<T>(dy + r * cols + c, g);
+            load8<T>(x + r * cols + c, xv);
+            const float rs = rstd[r];
 #pragma unroll
-        for (int i = 0; i < MAXV; ++i) {
-            const int c = (threadIdx.x + i * 256) * 8;
-            if (c < cols)
-#pragma unroll
-                for (int j = 0; j < 8; ++j) atomicAdd(dw + c + j, dwp[i][j]);
+            for (int j = 0; j < 8; ++j) acc[j] += g[j] * (xv[j] * rs);
         }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[rl][cl * 8 + j] = acc[j];
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        float s = 0.f;
+#pragma unroll 8
+        for (int r = 0; r < 32; ++r) s += red[r][threadIdx.x];
+        const int cc = blockIdx.x * 64 + threadIdx.x;
+        if (cc < cols) atomicAdd(dw + cc, s);
     }
 }
 
@@ -154,18 +168,23 @@ extern "C" int egomi_rmsnorm_bwd(const void* dy, const void* x, const void* w, c
     if (!dy || !x || !w || !rstd || !dx) return EGOMI_E_BADARG;
     if (rows <= 0 || cols <= 0 || cols % 8) return EGOMI_E_SHAPE;
     if (cols > 8192) return EGOMI_E_UNSUPPORTED;
-    // dw: partials live in registers across the rows of a block (one atomic per column and block) -> few blocks;
-    // without dw (frozen norm weights) one row per block keeps every CU's memory pipe full
-    const int grid = dw ? (rows < 1024 ? rows : 1024) : rows;
+    // one row per block keeps every CU's memory pipe full; the weight gradient, when wanted, is its own pass (above)
+    const int grid = rows;
+    if (dw) {
+        const int rseg = rows >= 2048 ? 8 : (rows >= 256 ? 2 : 1);
+        EGOMI_DISPATCH_DTYPE(dtype, EGOMI_LAUNCH(rmsnorm_dw_kernel<T>, dim3((cols + 63) / 64, rseg), dim3(256), 0, (hipStream_t)stream,
+                                                       (const T*)dy, (const T*)x, rstd, dw, rows, cols));
+        dw = nullptr;                                                   // the row kernel below only produces dx
+    }
     if (cols <= 2048) {
         EGOMI_DISPATCH_DTYPE(dtype, EGOMI_LAUNCH((rmsnorm_bwd_kernel<T, 1>), dim3(grid), dim3(256), 0, (hipStream_t)stream,
-                                                       (const T*)dy, (const T*)x, (const T*)w, rstd, (T*)dx, (const T*)dx_add, dw, rows, cols));
+                                                       (const T*)dy, (const T*)x, (const T*)w, rstd, (T*)dx, (const T*)dx_add, rows, cols));
     } else if (cols <= 4096) {
         EGOMI_DISPATCH_DTYPE(dtype, EGOMI_LAUNCH((rmsnorm_bwd_kernel<T, 2>), dim3(grid), dim3(256), 0, (hipStream_t)stream,
-                                                       (const T*)dy, (const T*)x, (const T*)w, rstd, (T*)dx, (const T*)dx_add, dw, rows, cols));
+                                                       (const T*)dy, (const T*)x, (const T*)w, rstd, (T*)dx, (const T*)dx_add, rows, cols));
     } else {
         EGOMI_DISPATCH_DTYPE(dtype, EGOMI_LAUNCH((rmsnorm_bwd_kernel<T, 4>), dim3(grid), dim3(256), 0, (hipStream_t)stream,
-                                                       (const T*)dy, (const T*)x, (const T*)w, rstd, (T*)dx, (const T*)dx_add, dw, rows, cols));
+                                                       (const T*)dy, (const T*)x, (const T*)w, rstd, (T*)dx, (const T*)dx_add, rows, cols));
     }
     return egomi_launch_status();
 }

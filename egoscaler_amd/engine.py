@@ -47,6 +47,8 @@ class Engine:
         self.ws = Workspace(device)
         self.prepared = False
         self.lm_wT, self.lm_wT_stale, self.lm_wT_ver = None, True, None     # padded transpose of lm_head for its dgrad (backward_logits)
+        self.grad_fresh = set()            # trainable weights whose main_grad must be overwritten, not accumulated, by their first wgrad
+        self._xt_last = {}                 # wgrad workspace name -> identity of the activation it currently holds transposed
         self.main_grad: Dict[str, torch.Tensor] = {}     # fp32 gradient buffers of trainable tensors
         self.trainable: Dict[str, bool] = {}
         self.ctx = None
@@ -134,6 +136,18 @@ class Engine:
     def zero_grad(self):
         for g in self.main_grad.values():
             g.zero_()
+        self.grad_fresh.clear()
+
+    def lazy_zero_ok(self, name):
+        """2-D weights whose whole gradient is written by _wgrad's product (decoder layers, lm_head, projector): their
+        buffers may skip the zero pass and be overwritten by the first product of the step."""
+        return self.w[name].dim() == 2 and (name.startswith("model.layers.") or name == "lm_head.weight" or name.startswith("model.point_proj."))
+
+    def flush_fresh(self):
+        """End of a backward: a buffer that no product touched this step must still read as zero."""
+        for n in list(self.grad_fresh):
+            self.main_grad[n].zero_()
+        self.grad_fresh.clear()
 
     # ------------------------------------------------------------------------------------ pieces
     def _attention(self, qkv, B, S, H, hd, out, causal, key_mask, scale, keep_P):
@@ -393,15 +407,24 @@ class Engine:
         if name not in self.trainable:
             return
         g = self.grad_buffer(name)
+        # a buffer still marked fresh has not been zeroed this step (lazy_zero_names): the first product overwrites it,
+        # which saves the zero pass and the read of C (26 GB each per step when every layer is trained)
+        acc = name not in self.grad_fresh
+        self.grad_fresh.discard(name)
         Mr, N = dY.shape
         K = X.shape[1]
         if self.dtype == torch.bfloat16 and Mr >= 128 and N * K >= 128 * 128:
             Mp = (Mr + 63) // 64 * 64
             dYt = ops.transpose(dY, ldo=Mp, out=self.ws.get(f"wg_dYt_{N}_{Mp}", (N, Mp), self.dtype))
-            Xt = ops.transpose(X, ldo=Mp, out=self.ws.get(f"wg_Xt_{K}_{Mp}", (K, Mp), self.dtype))
-            ops.mm(dYt, Xt, out=g, accumulate=True)
+            xname = f"wg_Xt_{K}_{Mp}"
+            Xt = self.ws.get(xname, (K, Mp), self.dtype)
+            xkey = (X.data_ptr(), X.stride(0), Mr)
+            if self._xt_last.get(xname) != xkey:                  # q, k, v (and gate, up) share their input: transposed once
+                ops.transpose(X, ldo=Mp, out=Xt)
+                self._xt_last[xname] = xkey
+            ops.mm(dYt, Xt, out=g, accumulate=acc)
         else:
-            ops.mm(dY, X, out=g, a_layout=1, b_layout=1, accumulate=True)
+            ops.mm(dY, X, out=g, a_layout=1, b_layout=1, accumulate=acc)
 
     def _bgrad(self, name, dY):
         if name in self.trainable:

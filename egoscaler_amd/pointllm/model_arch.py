@@ -288,15 +288,20 @@ class TrajPointLLMForCausalLM(nn.Module):
     # -- gradients ----------------------------------------------------------------------------------
     def _begin_backward(self):
         eng = self.engine
+        eng._xt_last.clear()                 # transposed-activation cache of engine._wgrad is valid within one backward only
         for n, p in self.named_parameters():
             if n in eng.trainable:
                 g = eng.grad_buffer(n)
                 fresh = (p.grad is None) if p.dtype == torch.float32 else (not self.accumulate_grads)
                 if fresh:
-                    g.zero_()
+                    if eng.lazy_zero_ok(n):
+                        eng.grad_fresh.add(n)          # overwritten by its first wgrad product (engine._wgrad)
+                    else:
+                        g.zero_()
 
     def _publish_grads(self):
         eng = self.engine
+        eng.flush_fresh()
         for n, p in self.named_parameters():
             if n in eng.trainable:
                 g = eng.main_grad[n]
