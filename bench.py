@@ -155,7 +155,7 @@ def main():
     model.engine.prepared = False
     model.train()
     opt = EgoAdamW(model, lr=2e-5)
-    sync = GradSync() if world > 1 else None
+    sync = GradSync(wire_dtype=torch.bfloat16) if world > 1 else None      # large fp32 gradient buffers cross xGMI as bf16
     model.engine.grad_sync = sync
 
     # ---- synthetic batch, resident in HBM before the timed region (rank r gets samples r*B .. r*B+B-1)

@@ -123,7 +123,7 @@ def train(args, model, train_data, val_data=None, device="cuda", log=print):
     """train.py:129-310.  Returns the list of per-epoch records."""
     rank, world = _rank_world()
     opt = EgoAdamW(model, lr=args.lr_llm)
-    sync = GradSync() if world > 1 else None
+    sync = GradSync(wire_dtype=torch.bfloat16 if model.engine.dtype == torch.bfloat16 else None) if world > 1 else None
     model.engine.grad_sync = sync
     start_epoch, global_step, best_ade = 0, 0, float("inf")
     os.makedirs(args.out_dir, exist_ok=True)

@@ -31,7 +31,17 @@ def _worker(rank, world, port, q):
         for n in ["lm_head", "norm", "embed"]:
             sync.ready(n, bufs[n])
         sync.finish()
-        q.put((rank, lo, hi, {n: float(b[0, 0]) for n, b in bufs.items()}, sync.grad_scale, sync.bytes))
+        # bf16 wire for large fp32 buffers: same sums (these values are exact in bf16), half the bytes, small ones untouched
+        s2 = GradSync(wire_dtype=torch.bfloat16, wire_min_bytes=1024)
+        big = torch.full((64, 16), float(rank + 1) * 0.5, dtype=torch.float32)
+        small = torch.full((4,), float(rank + 1), dtype=torch.float32)
+        noisy = torch.arange(1024, dtype=torch.float32) * (1.0 + 1e-3 * rank) + 0.123
+        s2.ready("big", big); s2.ready("small", small); s2.ready("noisy", noisy)
+        s2.finish()
+        exact = sum(torch.arange(1024, dtype=torch.float32) * (1.0 + 1e-3 * r) + 0.123 for r in range(world))
+        wire_ok = bool(torch.equal(big, torch.full((64, 16), 1.5)) and torch.equal(small, torch.full((4,), 3.0))
+                       and big.dtype == torch.float32 and float(((noisy - exact).abs() / exact.abs()).max()) < 2 ** -6)
+        q.put((rank, lo, hi, {n: float(b[0, 0]) for n, b in bufs.items()}, sync.grad_scale, sync.bytes, wire_ok, s2.bytes, noisy.clone()))
     finally:
         dist.destroy_process_group()
 
@@ -53,6 +63,8 @@ def test_grad_sync_world2_gloo():
     for r in res:
         assert r[3] == {"lm_head": total + 0.0, "norm": total + 2.0, "embed": total + 4.0}   # summed over ranks
         assert r[4] == 0.5 and r[5] == 3 * 5 * 3 * 4
+        assert r[6] and r[7] == 64 * 16 * 2 + 4 * 4 + 1024 * 2          # big and noisy travel as bf16, small stays fp32
+    assert torch.equal(res[0][8], res[1][8])                             # replicas hold identical reduced values
 
 
 def test_shard_range_and_single_process():
