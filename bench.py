@@ -7,7 +7,10 @@ One step = one pass of the hot path over one batch of synthetic input already re
   gradient all-reduce, overlapped) -> AdamW step.
 Config = BASELINE.json configs[1]: bs=8 per GPU, 8-frame 224x224 clips, 16-token text, bf16.
 
-  python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
+  python bench.py --gpus N --steps K --warmup W
+N>1: either launched by torch.distributed.run (RANK/LOCAL_RANK/WORLD_SIZE in the environment), or — from a plain shell —
+this process spawns one fresh child per GPU itself BEFORE touching the GPU and waits for them (no re-exec of a process
+that initialised HIP).  Every rank asserts dist.get_world_size() == N.
 Prints ONE JSON line on rank 0 (contract in the task statement), with `roofline` for the dominant
 kernel (the MFMA GEMM) from HIP events recorded in the timed region, and `cpu_baseline` (the CPU
 oracle timed on this box's host cores; rank 0, N=1 only).
@@ -48,9 +51,9 @@ def flops_per_sample(dims, S, S_traj, frozen_llm=True):
 
 
 def cpu_baseline(dims, Lp, threads):
-    """Oracle (CPU restatement of the reference) on a bounded sample: ONE clip, full PointBERT +
-    projector + splice + lm_head/CE, with 1 and 2 LLaMA layers at 7B width, fp32, forward+backward
-    (frozen-LLM mode).  Per-layer time = t(2)-t(1); whole model = t(1) + 31*(t(2)-t(1))."""
+    """Oracle (CPU restatement of the reference) on a bounded sample: ONE clip, full PointBERT + projector +
+    splice + lm_head/CE, with a 1-layer and a 4-layer slice of the LLaMA-7B-width stack, fp32, forward+backward (frozen-LLM
+    mode), on ALL host cores.  Per-layer time = (t(4)-t(1))/3; whole model = front + t(1) + 31 layers."""
     import copy
     from egoscaler_amd import synth
     from oracle import pointllm as OPL, llama as OL, pointcloud as OPC
@@ -62,7 +65,7 @@ def cpu_baseline(dims, Lp, threads):
     t_front = time.time() - t0
     toks, masks, _ = synth.synth_batch(dims, 1)
     times = {}
-    for L in (1, 2):
+    for L in (1, 4):
         dd = copy.deepcopy(dims)
         dd.lm.num_hidden_layers = L
         g = torch.Generator().manual_seed(0)
@@ -83,42 +86,121 @@ def cpu_baseline(dims, Lp, threads):
         loss.backward()
         times[L] = time.time() - t0
         del sd, logits, loss
-    per_layer = max(times[2] - times[1], 1e-6)
+    per_layer = max((times[4] - times[1]) / 3.0, 1e-6)
     total = t_front + times[1] + (dims.lm.num_hidden_layers - 1) * per_layer
     return {"value": 1.0 / total, "unit": "clips/s", "cores": threads, "kind": "port",
-            "sample": (f"1 clip (8x224x224) fwd+bwd fp32, frozen-LLM mode, oracle on {threads} threads: un-projection+pc_norm "
-                       f"{t_front:.2f}s, PointBERT+projector+1 LLaMA-7B layer+lm_head/CE {times[1]:.2f}s, extra layer {per_layer:.2f}s; "
-                       f"32-layer time extrapolated linearly = {total:.1f}s")}
+            "sample": (f"1 clip (8x224x224) fwd+bwd fp32, frozen-LLM mode, oracle on all {threads} host threads (os.cpu_count()): "
+                       f"un-projection+pc_norm {t_front:.2f}s, PointBERT+projector+1 LLaMA-7B-width layer+lm_head/CE {times[1]:.2f}s, 4-layer slice "
+                       f"{times[4]:.2f}s -> {per_layer:.2f}s per extra layer; 32-layer time extrapolated linearly = {total:.1f}s")}
+
+
+class SmiSampler:
+    """Engine clock and socket power while the timed region runs (rocm-smi as a child process every ~0.4 s): the dominant
+    kernel is power-limited, so a box-to-box difference in ms/step shows up here."""
+
+    def __init__(self, device_index):
+        import threading
+        self.dev, self.samples, self.on, self.stop = device_index, [], False, False
+        self.th = threading.Thread(target=self._run, daemon=True)
+        self.th.start()
+
+    def _read(self):
+        import re
+        import subprocess
+        try:
+            out = subprocess.run(["rocm-smi", "-d", str(self.dev), "--showclocks", "--showpower"], capture_output=True, text=True, timeout=5).stdout
+        except Exception:
+            return None
+        sclk = re.search(r"sclk clock level:?\s*\d*:?\s*\(?(\d+)Mhz", out)
+        pw = re.search(r"Power \(W\):\s*([\d.]+)", out)
+        return (int(sclk.group(1)) if sclk else None, float(pw.group(1)) if pw else None)
+
+    def _run(self):
+        while not self.stop:
+            if self.on:
+                r = self._read()
+                if r is not None:
+                    self.samples.append(r)
+            time.sleep(0.4)
+
+    def summary(self):
+        self.stop = True
+        self.th.join(6)
+        sc = sorted(x[0] for x in self.samples if x[0] is not None)
+        pw = sorted(x[1] for x in self.samples if x[1] is not None)
+        med = lambda v: v[len(v) // 2] if v else None
+        return {"sclk_mhz_median": med(sc), "sclk_mhz_min": sc[0] if sc else None, "socket_power_w_median": med(pw), "samples": len(self.samples),
+                "source": "rocm-smi --showclocks --showpower sampled during the timed region"}
+
+
+def launch_ranks(a):
+    """`python bench.py --gpus N` from a plain shell: one fresh child per GPU, started before this process makes any GPU
+    call (it never does), environment as torch.distributed.run would set it; exit code = worst child."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(a.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    return rc
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--mode", default="frozen", choices=["frozen", "unfrozen"], help="reference default flags freeze the LLM (model_arch.py:33-51)")
     ap.add_argument("--layers", type=int, default=None, help="debug only: fewer LLaMA layers (result is then marked invalid)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gemm-events", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo only to rehearse the N>1 code path on one GPU")
+    ap.add_argument("--dry-launch", action="store_true", help="launcher self-test: ranks rendezvous (gloo, host tensors), check the world size and exit without touching the GPU")
     a = ap.parse_args()
 
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(a))                    # parent: spawns the ranks, never touches the GPU itself
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
-    if world != a.gpus and world > 1:
+    if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
-    local = local % max(1, torch.cuda.device_count())        # rehearsal: several ranks may share one GPU under gloo
+    if a.dry_launch:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world > 1:
+            dist.init_process_group("gloo")
+            t = torch.tensor([float(rank)])
+            dist.all_reduce(t)
+            assert dist.get_world_size() == a.gpus and float(t) == world * (world - 1) / 2
+            dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps({"dry_launch": True, "n_gpus": world, "local_ranks": "0..%d" % (world - 1)}), flush=True)
+        return
+    ndev = torch.cuda.device_count()                         # counting devices does not initialise HIP
+    if a.backend == "nccl" and world > ndev:
+        raise SystemExit(f"--gpus {a.gpus} over RCCL needs {a.gpus} visible GPUs, found {ndev} (use --backend gloo to rehearse on fewer)")
+    local = local % max(1, ndev)                             # gloo rehearsal: several ranks may share one GPU
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if a.backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev)    # RCCL over xGMI
         else:
             dist.init_process_group("gloo")
+        if dist.get_world_size() != a.gpus:
+            raise SystemExit(f"process group has {dist.get_world_size()} ranks, --gpus {a.gpus}")
 
     from egoscaler_amd import ops, synth
     from egoscaler_amd.config import dims_7b
@@ -192,15 +274,25 @@ def main():
     if not a.no_gemm_events:
         prof = ops.GemmProfiler(min_flops=0, kernel_ids=(2,))          # the dominant kernel only: gemm_nt_bf16_8phase_kernel
         ops.PROFILER = prof
+    smi = SmiSampler(local) if rank == 0 else None
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]
     barrier()
     torch.cuda.synchronize()
+    if smi is not None:
+        smi.on = True
     t0 = time.perf_counter()
-    for _ in range(a.steps):
+    marks[0].record()
+    for i in range(a.steps):
         loss = step()
+        marks[i + 1].record()                                 # stream-ordered step boundaries: no host sync inside the timed region
     torch.cuda.synchronize()
     barrier()
     dt = time.perf_counter() - t0
+    if smi is not None:
+        smi.on = False
     ops.PROFILER = None
+    per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(a.steps))
+    ms_median = per_step[len(per_step) // 2] if len(per_step) % 2 else 0.5 * (per_step[len(per_step) // 2 - 1] + per_step[len(per_step) // 2])
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -213,25 +305,32 @@ def main():
     if prof is not None:
         sm = prof.summary()
         ach = sm["flops"] / (sm["ms"] * 1e-3) / 1e12 if sm["ms"] > 0 else 0.0
-        traffic = None
+        traffic, traffic_src = None, None
         pj = os.path.join(ROOT, "profiles", "pmc_gemm_latest.json")
         if os.path.exists(pj):
             try:
-                traffic = json.load(open(pj)).get("hbm_bytes_per_launch")
+                rec = json.load(open(pj))
+                traffic = rec.get("hbm_bytes_per_launch")
+                traffic_src = ("NOT measured in this run: read from profiles/pmc_gemm_latest.json = separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+                               "passes over `bench.py --steps 1 --warmup 1` (%s)" % rec.get("recorded", "round and commit in profiles/README.md"))
             except Exception:
                 traffic = None
         roof = {"bound": "mfma", "kernel": "gemm_nt_bf16_8phase_kernel (every launch in the timed region; the HIP-event bracket includes its slab-combine pass where the tail rows are K-sliced)", "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS,
-                "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
+                "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                 "launches_per_step": sm["launches"] // max(1, a.steps), "avg_launch_ms": round(sm["ms"] / max(1, sm["launches"]), 4),
                 "gemm_share_of_step": round(sm["ms"] / (dt * 1e3), 3)}
     out = {
         "metric": "clips/sec/GPU (8-frame 224^2, 16-token text) fwd+bwd",
         "value": round(clips_total / dt, 4), "unit": "clips/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
+        "ms_per_step_median": round(ms_median, 3), "ms_per_step_min_max": [round(per_step[0], 3), round(per_step[-1], 3)],
+        "value_is": "whole-job clips/s over all n_gpus (bench contract); the per-GPU figure the metric names is config.per_gpu_clips_per_s",
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
         "config": {"workload": "configs[1]: bs=8/GPU, 8-frame 224x224 RGB-D clip -> 8192-pt cloud, 16-token text, S=%d, PointBERT-v1.2 + LLaMA-7B shapes, "
                                "fwd+bwd+AdamW, %s-LLM mode (reference default flags)" % (S, a.mode),
-                   "global_batch": B * world, "seq_len": S, "parallelism": f"dp{world}", "per_gpu_clips_per_s": round(value, 4),
+                   "global_batch": B * world, "seq_len": S, "parallelism": f"dp{world}", "backend": ("rccl" if a.backend == "nccl" else "gloo") if world > 1 else None,
+                   "world_size_checked": (dist.get_world_size() if world > 1 else 1), "per_gpu_clips_per_s": round(value, 4),
+                   "grad_sync": (dict(sync.stats) if sync is not None else None),
                    "algorithmic_tflop_per_clip": round(fl["fwd_bwd"] / 1e12, 3),
                    "model_tflops_per_gpu": round(fl["fwd_bwd"] * value / 1e12, 2), "loss": round(float(loss), 4),
                    "valid": a.layers is None and B == 8},
@@ -239,9 +338,10 @@ def main():
     if roof is not None:
         out["roofline"] = roof
     if rank == 0:
+        out["clocks"] = smi.summary() if smi is not None else None
         if world == 1 and not a.no_cpu_baseline:
             try:
-                out["cpu_baseline"] = cpu_baseline(dims_7b(), Lp, min(16, os.cpu_count() or 1))
+                out["cpu_baseline"] = cpu_baseline(dims_7b(), Lp, os.cpu_count() or 1)
             except Exception as e:      # the oracle is a reported baseline; never fail the bench on it
                 out["cpu_baseline"] = {"value": None, "unit": "clips/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
         print(json.dumps(out), flush=True)

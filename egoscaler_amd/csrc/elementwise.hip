@@ -585,6 +585,9 @@ __global__ __launch_bounds__(1024) void ce_fwd_bwd_kernel(const T* logits, long 
         if (dlogits) for (int c = threadIdx.x; c < V; c += 1024) Cvt<T>::st(dlogits + row * ldd + c, 0.f);
         return;
     }
+    // in-place use (dlogits == logits): the target logit is read before the first barrier, i.e. before any thread
+    // of the block can have reached the gradient stores below
+    const float tl = Cvt<T>::ld(lr + t);
     float mx = -INFINITY;
     for (int c = threadIdx.x; c < V; c += 1024) mx = fmaxf(mx, Cvt<T>::ld(lr + c));
     mx = block_max(mx, red);
@@ -592,7 +595,7 @@ __global__ __launch_bounds__(1024) void ce_fwd_bwd_kernel(const T* logits, long 
     for (int c = threadIdx.x; c < V; c += 1024) s += __expf(Cvt<T>::ld(lr + c) - mx);
     s = block_sum(s, red);
     const float lse = mx + __logf(s);
-    if (threadIdx.x == 0) atomicAdd(loss_sum, lse - Cvt<T>::ld(lr + t));
+    if (threadIdx.x == 0) atomicAdd(loss_sum, lse - tl);
     if (dlogits) {
         const float sc = grad_scale / (float)(*count);
         for (int c = threadIdx.x; c < V; c += 1024) {
@@ -713,15 +716,58 @@ template <typename TI, typename TO>
 __global__ __launch_bounds__(256) void cast_kernel(const TI* in, TO* out, long long n) {
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) Cvt<TO>::st(out + i, Cvt<TI>::ld(in + i));
 }
+// 8 elements per thread (16-B / 32-B accesses): the gradient wire casts of dp.GradSync move GBs per step
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void cast8_kernel(const TI* in, TO* out, long long n8) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long long)gridDim.x * 256) {
+        float v[8];
+        load8<TI>(in + i * 8, v);
+        store8<TO>(out + i * 8, v);
+    }
+}
 extern "C" int egomi_cast(const void* in, int in_dtype, void* out, int out_dtype, int64_t n, egomi_stream_t stream) {
     if (!in || !out) return EGOMI_E_BADARG;
     if (n <= 0) return EGOMI_E_SHAPE;
     hipStream_t s = (hipStream_t)stream;
+    if (in_dtype != out_dtype && n % 8 == 0 && (((uintptr_t)in | (uintptr_t)out) & 15) == 0) {
+        const dim3 g8(ew_grid(n / 8)), b8(256);
+        if (in_dtype == EGOMI_F32 && out_dtype == EGOMI_BF16) { EGOMI_LAUNCH((cast8_kernel<float, bf16_t>), g8, b8, 0, s, (const float*)in, (bf16_t*)out, (long long)(n / 8)); return egomi_launch_status(); }
+        if (in_dtype == EGOMI_BF16 && out_dtype == EGOMI_F32) { EGOMI_LAUNCH((cast8_kernel<bf16_t, float>), g8, b8, 0, s, (const bf16_t*)in, (float*)out, (long long)(n / 8)); return egomi_launch_status(); }
+    }
     const dim3 g(ew_grid(n)), b(256);
     if (in_dtype == EGOMI_F32 && out_dtype == EGOMI_BF16) EGOMI_LAUNCH((cast_kernel<float, bf16_t>), g, b, 0, s, (const float*)in, (bf16_t*)out, (long long)n);
     else if (in_dtype == EGOMI_BF16 && out_dtype == EGOMI_F32) EGOMI_LAUNCH((cast_kernel<bf16_t, float>), g, b, 0, s, (const bf16_t*)in, (float*)out, (long long)n);
     else if (in_dtype == EGOMI_F32 && out_dtype == EGOMI_F32) EGOMI_LAUNCH((cast_kernel<float, float>), g, b, 0, s, (const float*)in, (float*)out, (long long)n);
     else if (in_dtype == EGOMI_BF16 && out_dtype == EGOMI_BF16) EGOMI_LAUNCH((cast_kernel<bf16_t, bf16_t>), g, b, 0, s, (const bf16_t*)in, (bf16_t*)out, (long long)n);
+    else return EGOMI_E_BADARG;
+    return egomi_launch_status();
+}
+
+// dp.GradSync, direct reduce-scatter: in [W, c] (the chunk every rank sent to this one, rank-major) -> out [c] = sum over
+// ranks, accumulated in fp32 in rank order 0..W-1 (the same order on every rank).  c % 8 == 0, 16-B aligned.
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void rank_sum_kernel(const TI* in, int W, long long c8, TO* out) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < c8; i += (long long)gridDim.x * 256) {
+        float acc[8], v[8];
+        load8<TI>(in + i * 8, acc);
+        for (int w = 1; w < W; ++w) {
+            load8<TI>(in + ((long long)w * c8 + i) * 8, v);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc[k] += v[k];
+        }
+        store8<TO>(out + i * 8, acc);
+    }
+}
+extern "C" int egomi_rank_sum(const void* in, int in_dtype, int W, int64_t c, void* out, int out_dtype, egomi_stream_t stream) {
+    if (!in || !out) return EGOMI_E_BADARG;
+    if (W <= 0 || c <= 0 || c % 8) return EGOMI_E_SHAPE;
+    if ((((uintptr_t)in | (uintptr_t)out) & 15) != 0) return EGOMI_E_BADARG;
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 g(ew_grid(c / 8)), b(256);
+    const long long c8 = c / 8;
+    if (in_dtype == EGOMI_BF16 && out_dtype == EGOMI_BF16) EGOMI_LAUNCH((rank_sum_kernel<bf16_t, bf16_t>), g, b, 0, s, (const bf16_t*)in, W, c8, (bf16_t*)out);
+    else if (in_dtype == EGOMI_BF16 && out_dtype == EGOMI_F32) EGOMI_LAUNCH((rank_sum_kernel<bf16_t, float>), g, b, 0, s, (const bf16_t*)in, W, c8, (float*)out);
+    else if (in_dtype == EGOMI_F32 && out_dtype == EGOMI_F32) EGOMI_LAUNCH((rank_sum_kernel<float, float>), g, b, 0, s, (const float*)in, W, c8, (float*)out);
     else return EGOMI_E_BADARG;
     return egomi_launch_status();
 }

@@ -38,11 +38,14 @@ def load_traj_file(path: str) -> dict:
     """{init_bbox, traj_quat, traj_rotvec} from .pkl/.pickle (restricted) or .npz."""
     if path.endswith(".npz"):
         with np.load(path, allow_pickle=False) as z:
-            return {k: z[k] for k in z.files}
-    with open(path, "rb") as f:
-        obj = _NumpyOnlyUnpickler(io.BytesIO(f.read())).load()
+            obj = {k: z[k] for k in z.files}
+    else:
+        with open(path, "rb") as f:
+            obj = _NumpyOnlyUnpickler(io.BytesIO(f.read())).load()
     if not isinstance(obj, dict) or "traj_rotvec" not in obj:
         raise ValueError(f"{path}: not an EgoScaler trajectory file")
+    if "traj_quat" not in obj and "traj" in obj:                  # assets/demo/trajectory.pkl names the quaternion track `traj`
+        obj["traj_quat"] = obj["traj"]
     return obj
 
 
@@ -120,13 +123,22 @@ class EgoScalerFiles:
 
 class FileTrajData:
     """Adapter with the `.batch(idx, device, max_traj_token)` interface of driver.SyntheticTrajData,
-    over files.  `encode(text) -> list[int]` is the caller's tokenizer (HF tokenizer in the reference)."""
+    over files.  `encode(text) -> list[int]` is the caller's tokenizer (HF tokenizer in the reference);
+    `norm` is the target normalisation (traj.TargetNorm: --do_norm / --do_standard, dataset.py:41-148)."""
 
-    def __init__(self, dims, files: EgoScalerFiles, encode, num_steps=20, max_desc_token=20, smooth=False):
+    def __init__(self, dims, files: EgoScalerFiles, encode, num_steps=20, max_desc_token=20, smooth=False, norm=None):
         self.dims, self.files, self.encode, self.num_steps, self.max_desc, self.smooth = dims, files, encode, num_steps, max_desc_token, smooth
+        self.norm = norm if norm is not None else T.TargetNorm(do_norm=True)
 
     def __len__(self):
         return len(self.files)
+
+    def fit_norm(self, save_dir=None):
+        """--do_standard on the train split: compute_mean_std over every trajectory file + norm_param.json (dataset.py:58-111)."""
+        self.norm.fit([self.files.sample(i)[3] for i in range(len(self.files))], self.num_steps, self.smooth)
+        if save_dir is not None:
+            self.norm.save(save_dir)
+        return self.norm
 
     def batch(self, idx, device, max_traj_token=160):
         return _file_batch(self, idx, device, max_traj_token)
@@ -142,24 +154,28 @@ def _file_batch(self, idx, device, max_traj_token=160):
     import torch
     from .driver import build_batch
     dims, N = self.dims, self.dims.pb.npoints
-    pcs, descs, trs, ids, steps = [], [], [], [], []
+    pcs, descs, trs, gts, mabs, ids = [], [], [], [], [], []
     for i in idx:
         image_id, pc, desc, tr = self.files.sample(int(i))
         if pc.shape[0] < N:
             raise ValueError(f"sample {image_id}: cloud has {pc.shape[0]} points, need {N}")
         sel = np.arange(N) * (pc.shape[0] // N)                      # same deterministic stride as the clip glue
         pcs.append(_pc_norm_np(pc[sel].astype(np.float64)).astype(np.float32))
-        tok = list(self.encode(desc))[: self.max_desc]
-        descs.append(tok)
+        descs.append(list(self.encode(desc))[: self.max_desc])       # --max_desc_token truncation (dataset.py:48)
         t = T.preprocess_traj(np.asarray(tr, dtype=np.float64), self.num_steps)           # traj_utils.py:3-39
         if self.smooth:
             t = T.smoothing_traj(t)
-        trs.append(np.clip(normalize_workspace(t), -1, 1).astype(np.float32))
+        v, m = self.norm.normalize(t)
+        trs.append(np.clip(v, -1, 1).astype(np.float32))
+        gts.append(t.astype(np.float32))
+        mabs.append(m.astype(np.float32))
         ids.append(image_id)
     L = max(len(d) for d in descs)
     L += L % 2
-    filler = 3                                                           # any ordinary vocabulary id; descriptions are left-aligned
-    desc = np.array([d + [filler] * (L - len(d)) for d in descs], dtype=np.int64)
-    return build_batch(dims, torch.from_numpy(desc).to(device), torch.from_numpy(np.stack(trs)).to(device),
-                       torch.from_numpy(np.stack(pcs)).to(device), max_traj_token, image_ids=torch.as_tensor(ids, device=device))
-
+    desc = np.full((len(descs), L), dims.tok.pad, dtype=np.int64)   # left-aligned; padding is masked out (dataset.py:161-177)
+    dmask = np.zeros((len(descs), L), dtype=bool)
+    for j, d in enumerate(descs):
+        desc[j, :len(d)], dmask[j, :len(d)] = d, True
+    dev = lambda a: torch.from_numpy(np.stack(a)).to(device)
+    return build_batch(dims, torch.from_numpy(desc).to(device), dev(trs), dev(pcs), max_traj_token, image_ids=torch.as_tensor(ids, device=device),
+                       desc_mask=torch.from_numpy(dmask).to(device), max_abs=dev(mabs), gt_trajs=dev(gts))

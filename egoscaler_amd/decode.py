@@ -77,6 +77,32 @@ class Decoder:
         ops.mm(last, self.eng.w["lm_head.weight"], out=self.lg)
         return self.lg
 
+    def prefill_chunked(self, input_ids, attention_mask, point_clouds, fps_start, total_new, chunk=16):
+        """prefill() for large batches (config 5: bs=256): the prompt pass runs `chunk` samples at a time (its activations are
+        what limits the batch, not the cache) and every chunk appends its K/V rows to its own slice of the static cache."""
+        B, S0 = input_ids.shape
+        eng, dev = self.eng, self.eng.device
+        lm = eng.dims.lm
+        H, hd, d = lm.num_attention_heads, lm.head_dim, lm.hidden_size
+        mask = torch.ones(B, S0, dtype=torch.bool, device=dev) if attention_mask is None else attention_mask.to(dev).bool()
+        self.mask = torch.cat([mask, torch.ones(B, self.Smax - S0, dtype=torch.bool, device=dev)], 1).to(torch.uint8).contiguous()
+        self.seq = torch.zeros(B, S0 + total_new, dtype=torch.int64, device=dev)
+        self.seq[:, :S0] = input_ids
+        for b0 in range(0, B, chunk):
+            b1 = min(B, b0 + chunk)
+
+            def sink(l, qkv, Bc, Sq, b0=b0):
+                for i in range(Bc):               # a batch slice of the [L,B,H,Smax,hd] cache is not contiguous over samples: one append each
+                    kv_append(qkv[i * Sq:(i + 1) * Sq, d:2 * d], qkv[i * Sq:(i + 1) * Sq, 2 * d:], qkv.stride(0), self.kc[l, b0 + i], self.vc[l, b0 + i],
+                              1, Sq, H, hd, self.Smax, 0)
+            pcs = None if point_clouds is None else point_clouds[b0:b1]
+            st = None if fps_start is None else fps_start[b0:b1]
+            hn = eng.forward_hidden(input_ids[b0:b1], mask[b0:b1], pcs, st, save=False, kv_sink=sink)
+            last = hn.view(b1 - b0, S0, -1)[:, -1].contiguous()
+            ops.mm(last, eng.w["lm_head.weight"], out=self.lg[b0:b1])
+        self.pos = S0
+        return self.lg
+
     # -- one decode step on static buffers: consumes self.tok, leaves logits in self.lg ---------------------
     def step(self, pos):
         eng = self.eng

@@ -1,11 +1,21 @@
 """Data parallelism for the training step: one process per GPU, samples sharded by rank, gradients
-summed with RCCL all-reduce over xGMI on a side stream while the rest of backward runs.
+summed over ranks on a side stream while the rest of backward runs.
 
-Reference: DeepSpeed ZeRO-1 engine.backward/step (train.py:92-125,183-184) and a DataLoader without
-DistributedSampler (train.py:72-82, every rank sees the same batches — fixed here by sharding).
-ZeRO-1 optimizer-state sharding is deliberately not reproduced: 288 GB per GPU
-holds the replicated fp32 state.  `backend="nccl"` is RCCL on ROCm; the same code runs on gloo/CPU
-tensors for the world_size-2 tests.
+Reference: DeepSpeed ZeRO-1 engine.backward/step (train.py:92-125,183-184: bf16 engine, 5e8-element reduce buckets) and a
+DataLoader without DistributedSampler (train.py:72-82, every rank sees the same batches — fixed here by sharding).
+ZeRO-1 optimizer-state sharding is deliberately not reproduced: 288 GB per GPU holds the replicated fp32
+state.  `backend="nccl"` is RCCL on ROCm; the same code runs on gloo / host tensors for the world_size-2 CPU tests.
+
+Exchange ("bf16 on the wire / fp32 accumulate, bucketed per decoder layer, direct reduce-scatter +
+all-gather across all 7 xGMI links rather than a ring"):
+  bucket = one flat buffer (a decoder layer's gradients are allocated flat by the engine; loose tensors are packed)
+  large buckets :  fp32 -> bf16 wire [W, c]  --all_to_all-->  chunk r of every rank  --egomi_rank_sum (fp32 accumulate,
+                   rank order 0..W-1)--> bf16 [c]  --all_gather-->  bf16 [W*c]  --> widened back into the fp32 buffer.
+                   Each GPU sends (W-1)/W of the bucket once per phase, to all peers at the same time (xGMI is
+                   point-to-point: a ring would push the whole bucket through ONE link per direction).
+  small buckets :  one fp32 all-reduce.
+Every rank ends with bit-identical values (the all-gather distributes one copy of each reduced chunk), so replicas do not
+drift.  Averaging (1/world) is folded into the optimizer's grad_scale.
 """
 import torch
 import torch.distributed as dist
@@ -19,52 +29,174 @@ def shard_range(global_batch: int, rank: int, world: int):
     return rank * per, (rank + 1) * per
 
 
+def _cast(src, dst):
+    """dst <- src (dtype change allowed).  Device tensors go through libegomi's vector cast; host tensors (gloo
+    rehearsal of the N>1 logic on CPUs) through torch."""
+    if src.is_cuda:
+        from . import ops
+        ops.cast(src, dst.dtype, out=dst)
+    else:
+        dst.copy_(src)
+
+
+def _rank_sum(chunks, out):
+    """chunks [W, c] -> out [c], fp32 accumulation in rank order."""
+    if chunks.is_cuda:
+        from . import ops
+        ops.rank_sum(chunks, out)
+    else:
+        acc = chunks[0].float().clone()
+        for w in range(1, chunks.shape[0]):
+            acc += chunks[w].float()
+        out.copy_(acc)
+
+
 class GradSync:
-    """Sum gradient buffers over ranks.  `ready(name, buf)` may be called as soon as a buffer is
-    final; the all-reduce is enqueued on a side stream (GPU) so it overlaps the remaining backward.
-    `finish()` joins.  Averaging (1/world) is folded into the optimizer's grad_scale.
+    """`ready(name, buf)` hands over a final gradient buffer (packed into the open bucket), `ready_flat(tag, flat)` a
+    buffer that already is a bucket (a decoder layer's flat gradient block); `flush()` closes the open bucket; buckets are
+    reduced on a side stream as soon as they close; `finish()` joins.  wire_dtype=torch.bfloat16: buckets of at least
+    `wire_min_bytes` cross the fabric as bf16 with fp32 accumulation (see the module docstring)."""
 
-    wire_dtype=torch.bfloat16: fp32 buffers of at least `wire_min_bytes` cross xGMI as bf16 and are widened back in
-    finish() — what the reference's DeepSpeed bf16 engine does with its (bf16) gradients (train.py:92-125), at half the
-    bytes: 0.55 instead of 1.1 GB per step in frozen-LLM mode, 13.5 instead of 27 GB with every parameter trained.
-    Every rank receives the same reduced values, so replicas stay bit-identical."""
-
-    def __init__(self, group=None, wire_dtype=None, wire_min_bytes=32 << 20):
+    def __init__(self, group=None, wire_dtype=None, wire_min_bytes=32 << 20, bucket_bytes=1 << 30):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.stream = None
-        self.pending = []          # (work, destination buffer, wire buffer or None)
-        self.bytes = 0             # bytes handed to the collective (wire size)
-        self.wire_dtype, self.wire_min_bytes = wire_dtype, wire_min_bytes
+        self.wire_dtype, self.wire_min_bytes, self.bucket_bytes = wire_dtype, wire_min_bytes, bucket_bytes
+        self.open, self.open_bytes = [], 0         # (name, buf) of the bucket being packed
+        self.pending = []                          # works of async host collectives
+        self._scratch = {}                         # persistent wire / packing buffers by (tag, numel, dtype)
+        self.stats = {"buckets": 0, "collective_calls": 0, "wire_bytes": 0}
+        self._bucket_id = 0
+        self._a2a_ok = True
+
+    # ------------------------------------------------------------------ bucket assembly
+    def begin_step(self):
+        self.stats = {"buckets": 0, "collective_calls": 0, "wire_bytes": 0}
+        self._bucket_id = 0
 
     def ready(self, name, buf: torch.Tensor):
         if self.world == 1:
             return
-        wire = None
-        if self.wire_dtype is not None and buf.dtype == torch.float32 and buf.numel() * 4 >= self.wire_min_bytes:
-            wire = buf.to(self.wire_dtype)                       # on the current stream, before the side stream picks it up
-        t = wire if wire is not None else buf
-        self.bytes += t.numel() * t.element_size()
-        if t.is_cuda:
+        self.open.append((name, buf))
+        self.open_bytes += buf.numel() * buf.element_size()
+        if self.open_bytes >= self.bucket_bytes:
+            self.flush()
+
+    def ready_flat(self, tag, flat: torch.Tensor):
+        if self.world == 1:
+            return
+        self.flush()
+        self._reduce(flat.view(-1), None)
+
+    def flush(self):
+        if self.world == 1 or not self.open:
+            return
+        bufs = [b for _, b in self.open]
+        self.open, self.open_bytes = [], 0
+        if len(bufs) == 1 and bufs[0].is_contiguous():
+            self._reduce(bufs[0].view(-1), None)
+        else:
+            self._reduce(None, bufs)
+
+    # ------------------------------------------------------------------ one bucket
+    def _buf(self, key, numel, dtype, device):
+        k = (key, numel, dtype)
+        t = self._scratch.get(k)
+        if t is None:
+            t = self._scratch[k] = torch.empty(numel, dtype=dtype, device=device)
+        return t
+
+    def _reduce(self, flat, parts):
+        """flat: a contiguous 1-D fp32 buffer reduced in place, or parts: tensors packed into one bucket and unpacked after."""
+        bid = self._bucket_id
+        self._bucket_id += 1
+        ref = flat if flat is not None else parts[0]
+        dev, cuda = ref.device, ref.is_cuda
+        n = flat.numel() if flat is not None else sum(p.numel() for p in parts)
+        W = self.world
+        use_wire = self.wire_dtype is not None and ref.dtype == torch.float32 and n * 4 >= self.wire_min_bytes
+        cur = torch.cuda.current_stream() if cuda else None
+        if cuda:
             if self.stream is None:
                 self.stream = torch.cuda.Stream()
-            self.stream.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(self.stream):
-                w = dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-        else:
-            w = dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-        self.pending.append((w, buf, wire))
+            self.stream.wait_stream(cur)                      # the bucket's gradients are final on the compute stream
+        ctx = torch.cuda.stream(self.stream) if cuda else _Null()
+        with ctx:
+            if use_wire:
+                c = -(-n // (W * 8)) * 8                       # per-rank chunk, 16-B aligned in bf16
+                wire = self._buf(("wire", bid), W * c, self.wire_dtype, dev)
+                if W * c > n:
+                    wire[n:].zero_()
+                self._pack(flat, parts, wire)
+                recv = self._buf(("recv", bid), W * c, self.wire_dtype, dev)
+                red = self._buf(("red", bid), c, self.wire_dtype, dev)
+                self._all_to_all(recv, wire, W, c)
+                _rank_sum(recv.view(W, c), red)
+                dist.all_gather_into_tensor(wire, red, group=self.group)
+                self.stats["collective_calls"] += 2
+                self.stats["wire_bytes"] += 2 * (W - 1) * c * wire.element_size()
+                self._unpack(wire, flat, parts)
+            else:
+                if flat is not None:
+                    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+                else:
+                    pk = self._buf(("pack", bid), n, ref.dtype, dev)
+                    self._pack(None, parts, pk)
+                    dist.all_reduce(pk, op=dist.ReduceOp.SUM, group=self.group)
+                    self._unpack(pk, None, parts)
+                self.stats["collective_calls"] += 1
+                self.stats["wire_bytes"] += 2 * (W - 1) * n * ref.element_size() // W
+        self.stats["buckets"] += 1
+
+    def _all_to_all(self, recv, send, W, c):
+        if self._a2a_ok:
+            try:
+                dist.all_to_all_single(recv, send, group=self.group)
+                return
+            except (RuntimeError, NotImplementedError):
+                self._a2a_ok = False                          # backend without all-to-all: gather everything, keep my chunk column
+        full = [torch.empty_like(send) for _ in range(W)]
+        dist.all_gather(full, send, group=self.group)
+        for w in range(W):
+            recv[w * c:(w + 1) * c].copy_(full[w][self.rank * c:(self.rank + 1) * c])
+
+    @staticmethod
+    def _pack(flat, parts, dst):
+        if flat is not None:
+            _cast(flat, dst[:flat.numel()])
+            return
+        o = 0
+        for p in parts:
+            _cast(p.reshape(-1), dst[o:o + p.numel()])
+            o += p.numel()
+
+    @staticmethod
+    def _unpack(src, flat, parts):
+        if flat is not None:
+            _cast(src[:flat.numel()], flat)
+            return
+        o = 0
+        for p in parts:
+            if p.is_contiguous():
+                _cast(src[o:o + p.numel()], p.view(-1))
+            else:
+                p.copy_(src[o:o + p.numel()].view(p.shape))
+            o += p.numel()
 
     def finish(self):
-        for w, _, _ in self.pending:
-            w.wait()
+        self.flush()
         if self.stream is not None:
             torch.cuda.current_stream().wait_stream(self.stream)
-        for _, buf, wire in self.pending:
-            if wire is not None:
-                buf.copy_(wire)                                  # widen back into the fp32 main_grad buffer
-        self.pending = []
 
     @property
     def grad_scale(self):
         return 1.0 / self.world
+
+
+class _Null:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False

@@ -27,35 +27,76 @@ from .dp import GradSync, shard_range
 from .optim import EgoAdamW, linear_warmup_lr
 
 
-def build_batch(dims, desc_ids, trajs, pcrgbs, max_traj_token=160, image_ids=None, steps=None):
-    """desc_ids i64 [B,Ld] (description tokens), trajs f32 [B,T,6] in [-1,1], pcrgbs f32 [B,N,6] (device).
-    Sequence: [bos] desc_a <point_start> <point_patch>xP <point_end> desc_b | <ts> (p*6 <tsep>)*T <te> eos pad
-    (SURVEY.md §8d); prompts run up to the first <tsep> of sample 0 (dataset.py:180-182)."""
+def collate(dims, image_ids, pcrgbs, desc_tokens, desc_masks, traj_tokens, traj_masks, gt_trajs, max_abs, sep_ids=()):
+    """`CustomDataset.collate_fn` (dataset.py:150-194) on device tensors that are already stacked:
+    tokens = desc | <sep> ids | traj ; masks likewise (the <sep> ids are always attended) ; prompts run up to and including
+    the first <tsep> of SAMPLE 0 (dataset.py:180-182) ; 'trajectory_masks' is the token-level trajectory mask."""
+    dev = pcrgbs.device
+    B = desc_tokens.shape[0]
+    sep = torch.as_tensor(list(sep_ids), dtype=torch.int64, device=dev).reshape(1, -1).expand(B, -1)
+    tokens = torch.cat((desc_tokens, sep, traj_tokens), dim=-1)
+    masks = torch.cat((desc_masks.bool(), torch.ones_like(sep), traj_masks.bool()), dim=-1)      # bool ++ int64 -> int64 0/1, as in the reference
+    hit = (tokens[0] == dims.tok.tsep).nonzero()
+    if hit.numel() == 0:
+        raise IndexError("no <tsep> in the first sample")                  # the reference's [1][0] raises IndexError here too
+    pos = int(hit[0, 0])
+    return {"image_ids": image_ids, "pcrgbs": pcrgbs, "prompts": tokens[:, :pos + 1], "prompt_masks": masks[:, :pos + 1],
+            "tokens": tokens, "attention_masks": masks, "trajectories": gt_trajs, "trajectory_masks": traj_masks.bool(),
+            "max_abs": max_abs}
+
+
+def build_batch(dims, desc_ids, trajs, pcrgbs, max_traj_token=160, image_ids=None, steps=None, desc_mask=None, max_abs=None,
+                sep_ids=(), gt_trajs=None):
+    """The per-sample half the release lacks (`CustomDataset.__getitem__`) + collate, on the device.
+    desc_ids i64 [B,Ld] (description tokens, padded), desc_mask bool [B,Ld] (False on padding; None = all real),
+    trajs f32 [B,T,6] in [-1,1] (already normalised), pcrgbs f32 [B,N,6].
+    Description part: [bos] desc_a <point_start> <point_patch>xP <point_end> desc_b; trajectory part:
+    <ts> (p*6 <tsep>)*T <te> eos pad...  Padding positions of the description carry mask False into `attention_masks`
+    and `prompt_masks` exactly like the tokenizer's `desc_masks` do in the reference (dataset.py:161-177)."""
     tok, P = dims.tok, dims.pb.point_token_len
     dev = pcrgbs.device
     B, Ld = desc_ids.shape
-    a, b = desc_ids[:, :Ld // 2], desc_ids[:, Ld // 2:]
+    dm = torch.ones(B, Ld, dtype=torch.bool, device=dev) if desc_mask is None else desc_mask.to(dev).bool()
+    h = Ld // 2
     col = lambda v: torch.full((B, 1), v, dtype=torch.int64, device=dev)
-    head = torch.cat([col(tok.bos), a, col(tok.point_start), torch.full((B, P), tok.point_patch, dtype=torch.int64, device=dev),
-                      col(tok.point_end), b], 1)
+    one = torch.ones(B, 1, dtype=torch.bool, device=dev)
+    head = torch.cat([col(tok.bos), desc_ids[:, :h], col(tok.point_start), torch.full((B, P), tok.point_patch, dtype=torch.int64, device=dev),
+                      col(tok.point_end), desc_ids[:, h:]], 1)
+    head_mask = torch.cat([one, dm[:, :h], one, torch.ones(B, P, dtype=torch.bool, device=dev), one, dm[:, h:]], 1)
     tt, tm = T.tokenize_batch(trajs, tok, max_traj_token, steps=steps)
-    tokens = torch.cat([head, tt], 1)
-    masks = torch.cat([torch.ones_like(head, dtype=torch.bool), tm], 1)
-    pos = int((tokens[0] == tok.tsep).nonzero()[0, 0])
-    return {"image_ids": image_ids if image_ids is not None else torch.arange(B, device=dev), "pcrgbs": pcrgbs,
-            "prompts": tokens[:, :pos + 1], "prompt_masks": masks[:, :pos + 1], "tokens": tokens, "attention_masks": masks,
-            "trajectories": trajs, "trajectory_masks": tm, "max_abs": torch.ones(B, 6, device=dev)}
+    return collate(dims, image_ids if image_ids is not None else torch.arange(B, device=dev), pcrgbs, head, head_mask, tt, tm,
+                   trajs if gt_trajs is None else gt_trajs, torch.ones(B, 6, device=dev) if max_abs is None else max_abs, sep_ids)
 
 
 class SyntheticTrajData:
-    """Seeded synthetic samples: RGB-D clip -> un-projection -> 8192-point cloud (A1, A2 on the device),
-    uniform description ids, smooth random trajectories."""
+    """Seeded synthetic samples: RGB-D clip -> un-projection -> 8192-point cloud (A1, A2 on the device), uniform description
+    ids of varying length (padded to `max_desc_token` with mask False when that is set), smooth random trajectories in
+    workspace metres / rotation vectors that go through `norm` (traj.TargetNorm: --do_norm / --do_standard / neither)."""
 
-    def __init__(self, dims, n_samples, frames=2, size=64, text_len=16, num_steps=20, seed=42):
+    def __init__(self, dims, n_samples, frames=2, size=64, text_len=16, num_steps=20, seed=42, norm=None, max_desc_token=None,
+                 ragged_text=False):
         self.dims, self.n, self.frames, self.size, self.text_len, self.num_steps, self.seed = dims, n_samples, frames, size, text_len, num_steps, seed
+        self.norm = norm if norm is not None else T.TargetNorm()
+        self.max_desc, self.ragged = max_desc_token, ragged_text
 
     def __len__(self):
         return self.n
+
+    def raw_traj(self, i):
+        """[num_steps, 6]: in [-1,1] for mode 'none', else workspace metres + rotation vectors (radians)."""
+        g = synth._rng(self.seed + int(i), 0xDA7A)
+        desc = g.integers(3, min(self.dims.tok.point_patch, self.dims.lm.vocab_size), size=self.text_len)
+        base = g.uniform(-0.6, 0.6, size=(1, 6))
+        walk = np.clip(base + np.cumsum(g.normal(0, 0.03, size=(self.num_steps, 6)), 0), -1, 1)
+        n_real = int(g.integers(max(2, self.text_len // 2), self.text_len + 1)) if self.ragged else self.text_len
+        return desc, n_real, (walk if self.norm.mode == "none" else T.denorm(walk[None])[0])
+
+    def fit_norm(self, save_dir=None):
+        """train split with --do_standard: compute_mean_std + norm_param.json (dataset.py:58-66,80-111)."""
+        self.norm.fit([self.raw_traj(i)[2] for i in range(self.n)], self.num_steps)
+        if save_dir is not None:
+            self.norm.save(save_dir)
+        return self.norm
 
     def batch(self, idx, device, max_traj_token=160):
         dims, H = self.dims, self.size
@@ -67,16 +108,23 @@ class SyntheticTrajData:
         if int(cnt.min()) < dims.pb.npoints:
             raise ValueError("clip has fewer valid pixels than npoints")
         pc = ops.pc_norm(pts, col)
-        desc, trs = [], []
-        for i in idx:
-            g = synth._rng(self.seed + int(i), 0xDA7A)
-            desc.append(g.integers(3, min(dims.tok.point_patch, dims.lm.vocab_size), size=self.text_len))
-            base = g.uniform(-0.6, 0.6, size=(1, 6))
-            walk = np.cumsum(g.normal(0, 0.03, size=(self.num_steps, 6)), 0)
-            trs.append(np.clip(base + walk, -1, 1))
-        desc = torch.from_numpy(np.stack(desc)).to(device)
-        trs = torch.from_numpy(np.stack(trs).astype(np.float32)).to(device)
-        return build_batch(dims, desc, trs, pc, max_traj_token, image_ids=torch.as_tensor(list(idx), device=device))
+        Ld = self.text_len if self.max_desc is None else int(self.max_desc)
+        Ld += Ld % 2
+        desc = np.full((len(idx), Ld), dims.tok.pad, dtype=np.int64)
+        dmask = np.zeros((len(idx), Ld), dtype=bool)
+        trs, gts, mabs = [], [], []
+        for j, i in enumerate(idx):
+            d, n_real, raw = self.raw_traj(i)
+            n_real = min(n_real, Ld)                                   # --max_desc_token truncates (dataset.py:48)
+            desc[j, :n_real], dmask[j, :n_real] = d[:n_real], True
+            v, m = self.norm.normalize(raw)
+            trs.append(np.clip(v, -1, 1))
+            gts.append(raw)
+            mabs.append(m)
+        to = lambda a, dt: torch.from_numpy(np.stack(a).astype(dt)).to(device)
+        return build_batch(dims, torch.from_numpy(desc).to(device), to(trs, np.float32), pc, max_traj_token,
+                           image_ids=torch.as_tensor([int(i) for i in idx], device=device), desc_mask=torch.from_numpy(dmask).to(device),
+                           max_abs=to(mabs, np.float32), gt_trajs=to(gts, np.float32))
 
 
 def _rank_world():
@@ -85,46 +133,82 @@ def _rank_world():
     return 0, 1
 
 
+def micro_batch_per_rank(bs, grad_accum_steps, world):
+    """DeepSpeed arithmetic of train.py:92-96: train_batch_size = bs = micro * grad_accum_steps * world."""
+    return max(1, -(-int(bs) // (max(1, int(grad_accum_steps)) * max(1, int(world)))))
+
+
 @torch.no_grad()
 def run_validation(model, data, args, device, max_batches=None):
-    """Generation + metrics on the rank's shard (train.py:207-264): prompts up to the first <tsep>,
-    greedy decode of the remaining positions, de-tokenise, pad with the last step, ADE / FDE."""
+    """Generation + metrics on the rank's shard (train.py:207-264, evaluate.py:104-154): prompts up to the first <tsep>,
+    `generate` of the remaining positions (sampling with the reference's defaults top_k 50 / top_p 0.95 / T 1.0 unless
+    args.val_sample is False -> greedy), cut at eos, de-tokenise, de-normalise (dataset.denorm), pad with the last step,
+    ADE / FDE / GD; sums are all-reduced over ranks so that every rank (and the best-checkpoint choice) sees the same means.
+
+    Metrics: 'ADE'/'FDE' use the documented [T,D] form of metrics.py:38-55,7-27; 'ADE_as_called' is what the reference's
+    drivers log (they pass [1,T,6], so the norm runs over TIME: SURVEY.md §0.1); 'GD' is metrics.py:61-87 on the rotation
+    vectors [T,3] (the reference's own call passes [1,T,6] and raises inside scipy)."""
     dims = model.dims
     rank, world = _rank_world()
+    norm = getattr(data, "norm", None) or T.TargetNorm()
+    sample = bool(getattr(args, "val_sample", True))
+    per = micro_batch_per_rank(args.bs, 1, world)
     model.eval()
-    ades, fdes, dump = [], [], {}
-    order = list(range(len(data)))
-    nb = len(order) // (args.bs * world)
+    sums = np.zeros(5)                                   # ADE, FDE, ADE_as_called, GD, n
+    dump = {}
+    nb = len(data) // (per * world)
     for bi in range(nb if max_batches is None else min(nb, max_batches)):
-        lo, hi = shard_range(args.bs * world, rank, world)
-        idx = order[bi * args.bs * world + lo: bi * args.bs * world + hi]
+        lo, hi = shard_range(per * world, rank, world)
+        idx = list(range(bi * per * world + lo, bi * per * world + hi))
         batch = data.batch(idx, device, args.max_traj_token)
         prompts, tokens = batch["prompts"], batch["tokens"]
         max_new = tokens.shape[1] - prompts.shape[1]
         out = model.generate(input_ids=prompts, attention_mask=batch["prompt_masks"], point_clouds=batch["pcrgbs"], max_length=max_new,
-                             do_sample=False, fps_start=torch.zeros(len(idx), dtype=torch.int32, device=device))
+                             do_sample=sample, fps_start=torch.zeros(len(idx), dtype=torch.int32, device=device))
         gen_ids = out.sequences[:, prompts.shape[1]:]
         # the prompt holds the first step; prepend its six tokens + <tsep> so step 0 is parsed like the rest
-        first = prompts[:, -7:]
-        vals, n = T.detokenize_batch(torch.cat([first, gen_ids], 1), dims.tok, args.num_steps + 4)
+        vals, n = T.detokenize_batch(torch.cat([prompts[:, -7:], gen_ids], 1), dims.tok, args.num_steps + 4)
         gt = batch["trajectories"]
         Tn = gt.shape[1]
-        ade, fde = T.metrics_batch(vals[:, :Tn].contiguous(), torch.clamp(n, max=Tn), gt)
-        ok = n > 0
-        ades += ade[ok].tolist()
-        fdes += fde[ok].tolist()
+        n = torch.clamp(n, max=Tn)
+        vals_h, n_h = vals[:, :Tn].cpu().numpy(), n.cpu().numpy()
+        for j in range(len(idx)):                                           # pad with the last parsed step (train.py:252-256)
+            if 0 < n_h[j] < Tn:
+                vals_h[j, n_h[j]:] = vals_h[j, n_h[j] - 1]
+        gen = norm.denorm(vals_h, batch["max_abs"].cpu().numpy())
+        gen_d = torch.from_numpy(np.ascontiguousarray(gen, dtype=np.float32)).to(device)
+        ade, fde = T.metrics_batch(gen_d, None, gt)
+        ade, fde, gt_h = ade.cpu().numpy(), fde.cpu().numpy(), gt.cpu().numpy()
         for j, i in enumerate(idx):
-            dump[int(i)] = {"gen_traj": T.denorm(vals[j:j + 1, :max(1, min(int(n[j]), Tn))].cpu().numpy())[0].tolist()}
+            if n_h[j] <= 0:
+                continue                                                     # detokenize_traj returned None (train.py:249-250)
+            sums += [ade[j], fde[j], T.average_displacement_error(gen[j][None], gt_h[j][None]),
+                     T.anglar_distance(gen[j][:, 3:6].astype(np.float64), gt_h[j][:, 3:6].astype(np.float64)), 1.0]
+            dump[int(i)] = gen[j].tolist()                                   # evaluate.py:150
+    if world > 1:
+        t = torch.from_numpy(sums).to(device)
+        dist.all_reduce(t)
+        sums = t.cpu().numpy()
     model.train()
-    return {"ADE": float(np.mean(ades)) if ades else float("nan"), "FDE": float(np.mean(fdes)) if fdes else float("nan"), "n": len(ades)}, dump
+    k = max(sums[4], 1.0)
+    nan = float("nan")
+    return {"ADE": sums[0] / k if sums[4] else nan, "FDE": sums[1] / k if sums[4] else nan, "ADE_as_called": sums[2] / k if sums[4] else nan,
+            "GD": sums[3] / k if sums[4] else nan, "n": int(sums[4])}, dump
 
 
 def train(args, model, train_data, val_data=None, device="cuda", log=print):
-    """train.py:129-310.  Returns the list of per-epoch records."""
+    """train.py:129-310.  Returns the list of per-epoch records.
+
+    Batch arithmetic (train.py:92-96): `--bs` is the optimizer batch of the whole job; each rank runs
+    `--grad_accum_steps` micro-batches of ceil(bs / accum / world) samples per optimizer step, gradients accumulate in the
+    fp32 main_grad buffers, ONE gradient sync + ONE AdamW step follow the last micro-batch (grad scale 1/(accum*world)).
+    LR: HF linear schedule with warm-up over int(total/5) steps then decay to 0 (train.py:113-116), advanced once per
+    optimizer step."""
     rank, world = _rank_world()
-    opt = EgoAdamW(model, lr=args.lr_llm)
+    accum = max(1, int(getattr(args, "grad_accum_steps", 1) or 1))
+    micro = micro_batch_per_rank(args.bs, accum, world)
+    opt = EgoAdamW(model, lr=float(args.lr_llm))
     sync = GradSync(wire_dtype=torch.bfloat16 if model.engine.dtype == torch.bfloat16 else None) if world > 1 else None
-    model.engine.grad_sync = sync
     start_epoch, global_step, best_ade = 0, 0, float("inf")
     os.makedirs(args.out_dir, exist_ok=True)
     latest = os.path.join(args.out_dir, "latest_model.pt")
@@ -134,7 +218,13 @@ def train(args, model, train_data, val_data=None, device="cuda", log=print):
         opt.load_state_dict(ck["optimizer_state_dict"])
         start_epoch, global_step, best_ade = ck["epoch"] + 1, ck["global_step"], ck.get("best_ade", best_ade)
         opt.resync_masters()
-    steps_per_epoch = len(train_data) // (args.bs * world)
+    if getattr(train_data, "norm", None) is not None and train_data.norm.mode == "standard":     # dataset.py:58-66
+        if train_data.norm.mean is None:
+            train_data.fit_norm(args.out_dir if rank == 0 else None)
+        if val_data is not None and getattr(val_data, "norm", None) is not train_data.norm:
+            val_data.norm = train_data.norm
+    per_step = micro * accum * world                                                   # samples per optimizer step (== bs when divisible)
+    steps_per_epoch = len(train_data) // per_step
     total_steps = steps_per_epoch * args.epochs
     history = []
     model.train()
@@ -143,17 +233,24 @@ def train(args, model, train_data, val_data=None, device="cuda", log=print):
         order = g.permutation(len(train_data))
         run = torch.zeros((), device=device)
         for it in range(steps_per_epoch):
-            lo, hi = shard_range(args.bs * world, rank, world)
-            idx = order[it * args.bs * world + lo: it * args.bs * world + hi]
-            batch = train_data.batch(idx, device, args.max_traj_token)
-            loss = model.loss_and_backward(batch["tokens"], batch["attention_masks"], batch["pcrgbs"], batch["prompts"].shape[1],
-                                           model.dims.tok.pad, fps_start=torch.zeros(len(idx), dtype=torch.int32, device=device))
+            for a in range(accum):
+                base = it * per_step + a * micro * world
+                lo, hi = shard_range(micro * world, rank, world)
+                idx = order[base + lo: base + hi]
+                batch = train_data.batch(idx, device, args.max_traj_token)
+                last = a == accum - 1
+                model.accumulate_grads = a > 0                                      # first micro-batch overwrites (optimizer.zero_grad(), train.py:159)
+                model.engine.grad_sync = sync if last else None                     # reduce once, after the last micro-batch
+                loss = model.loss_and_backward(batch["tokens"], batch["attention_masks"], batch["pcrgbs"], batch["prompts"].shape[1],
+                                               model.dims.tok.pad, fps_start=torch.zeros(len(idx), dtype=torch.int32, device=device))
+                run += loss / accum
+            model.accumulate_grads = False
             if sync is not None:
                 sync.finish()
-            opt.step(grad_scale=sync.grad_scale if sync is not None else 1.0, lr=linear_warmup_lr(args.lr_llm, global_step, total_steps))
-            run += loss
+            opt.step(grad_scale=1.0 / (accum * world), lr=linear_warmup_lr(float(args.lr_llm), global_step, total_steps))
             global_step += 1
-        rec = {"epoch": epoch, "train_loss": float(run) / max(1, steps_per_epoch), "global_step": global_step}
+        rec = {"epoch": epoch, "train_loss": float(run) / max(1, steps_per_epoch), "global_step": global_step,
+               "learning_rate": linear_warmup_lr(float(args.lr_llm), global_step, total_steps)}
         if val_data is not None:
             m, _ = run_validation(model, val_data, args, device, max_batches=getattr(args, "val_batches", None))
             rec.update(m)
@@ -167,20 +264,30 @@ def train(args, model, train_data, val_data=None, device="cuda", log=print):
             ck = {"epoch": epoch, "model_state_dict": {k: v.detach().cpu() for k, v in model.state_dict().items()},
                   "optimizer_state_dict": opt.state_dict_cpu(), "scheduler_state_dict": {"last_step": global_step}, "global_step": global_step}
             torch.save(ck, latest)                                                      # train.py:287-296
-            if val_data is not None and rec.get("ADE", float("inf")) < best_ade:
+            if val_data is not None and rec.get("ADE", float("inf")) < best_ade:        # metrics are all-reduced: same choice on any rank
                 best_ade = rec["ADE"]
                 ck["best_ade"] = best_ade
                 torch.save(ck, os.path.join(args.out_dir, "best_model_ade.pt"))         # train.py:298-308
+    model.engine.grad_sync = None
     return history
 
 
 def evaluate(args, model, data, split="test", device="cuda"):
-    """evaluate.py:70-170: load best_model_ade.pt, generate on the split, dump {split}_gen_trajs.json."""
+    """evaluate.py:70-170: load best_model_ade.pt, generate on the split, dump {split}_gen_trajs.json
+    ({image_id: [[x,y,z,rx,ry,rz], ...]}, evaluate.py:150,167-170); --do_standard statistics come from
+    `{checkpoint_dir}/norm_param.json` (evaluate.py:91 hands checkpoint_dir to the dataset as save_dir)."""
     best = os.path.join(args.checkpoint_dir, "best_model_ade.pt")
     if os.path.exists(best):
         model.load_state_dict(torch.load(best, map_location="cpu", weights_only=True)["model_state_dict"])
+    norm = getattr(data, "norm", None)
+    if norm is not None and norm.mode == "standard" and norm.mean is None:
+        norm.load(args.checkpoint_dir)
     metrics, dump = run_validation(model, data, args, device)
-    rank, _ = _rank_world()
+    rank, world = _rank_world()
+    if world > 1:
+        parts = [None] * world
+        dist.all_gather_object(parts, dump)
+        dump = {k: v for p in parts for k, v in p.items()}
     if rank == 0:
         with open(os.path.join(args.checkpoint_dir, f"{split}_gen_trajs.json"), "w") as f:
             json.dump(dump, f)
@@ -211,6 +318,8 @@ def parse_args(argv=None):
     ap.add_argument("--n_train", type=int, default=64)
     ap.add_argument("--n_val", type=int, default=16)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--val_greedy", dest="val_sample", action="store_false",
+                    help="validate with greedy decoding instead of the reference's sampling defaults (model_arch.py:82-88)")
     return ap.parse_args(argv)
 
 
@@ -231,9 +340,10 @@ def main(argv=None):
         sd = synth.synth_state_dict(dims, 0)
         model.load_state_dict({k: (v.to(dtype) if v.dtype.is_floating_point else v) for k, v in sd.items()})
     a.checkpoint_dir = a.checkpoint_dir or a.out_dir
-    val = SyntheticTrajData(dims, a.n_val, num_steps=a.num_steps, seed=977)
+    norm = T.TargetNorm(a.do_norm, a.do_standard)
+    val = SyntheticTrajData(dims, a.n_val, num_steps=a.num_steps, seed=977, norm=norm, max_desc_token=a.max_desc_token, ragged_text=True)
     if a.mode == "train":
-        train(a, model, SyntheticTrajData(dims, a.n_train, num_steps=a.num_steps), val, dev)
+        train(a, model, SyntheticTrajData(dims, a.n_train, num_steps=a.num_steps, norm=norm, max_desc_token=a.max_desc_token, ragged_text=True), val, dev)
     else:
         print(json.dumps(evaluate(a, model, val, "test", dev)))
     if world > 1:

@@ -47,9 +47,12 @@ class Engine:
         self.ws = Workspace(device)
         self.prepared = False
         self.lm_wT, self.lm_wT_stale, self.lm_wT_ver = None, True, None     # padded transpose of lm_head for its dgrad (backward_logits)
+        self.param_ref = {}                # name -> nn.Parameter (set by the model shell): in-place updates by torch optimizers bump ITS
+                                           # _version, not that of the `.data` aliases held in self.w
         self.grad_fresh = set()            # trainable weights whose main_grad must be overwritten, not accumulated, by their first wgrad
         self._xt_last = {}                 # wgrad workspace name -> identity of the activation it currently holds transposed
         self.main_grad: Dict[str, torch.Tensor] = {}     # fp32 gradient buffers of trainable tensors
+        self.layer_flat: Dict[int, torch.Tensor] = {}    # decoder layer -> ONE flat fp32 block holding all of its gradients (= a DP bucket)
         self.trainable: Dict[str, bool] = {}
         self.ctx = None
         self.grad_sync = None          # optional dp.GradSync: notified when a gradient buffer is final
@@ -61,6 +64,12 @@ class Engine:
     def _notify(self, name):
         if self.grad_sync is not None and name in self.trainable and name in self.main_grad:
             self.grad_sync.ready(name, self.main_grad[name])
+
+    def _notify_layer(self, l):
+        """A decoder layer's gradients are final: its flat block goes out as one bucket (bucketed per layer,
+        reverse layer order, overlapped with the rest of backward)."""
+        if self.grad_sync is not None and l in self.layer_flat:
+            self.grad_sync.ready_flat(f"layer{l}", self.layer_flat[l])
 
     # ------------------------------------------------------------------------------------ setup
     def prepare(self):
@@ -129,9 +138,24 @@ class Engine:
     def grad_buffer(self, name):
         g = self.main_grad.get(name)
         if g is None:
+            if name.startswith("model.layers."):
+                self._alloc_layer_grads(int(name.split(".")[2]))
+                return self.main_grad[name]
             g = torch.zeros(self.w[name].shape, dtype=torch.float32, device=self.device)
             self.main_grad[name] = g
         return g
+
+    def _alloc_layer_grads(self, l):
+        """All trainable tensors of decoder layer l share one flat fp32 block (each starts on a 256-B boundary)."""
+        names = [n for n in self.layer_param_names(l) if n in self.trainable]
+        offs, total = [], 0
+        for n in names:
+            offs.append(total)
+            total += (self.w[n].numel() + 63) // 64 * 64
+        flat = torch.zeros(total, dtype=torch.float32, device=self.device)
+        self.layer_flat[l] = flat
+        for n, o in zip(names, offs):
+            self.main_grad[n] = flat[o:o + self.w[n].numel()].view(self.w[n].shape)
 
     def zero_grad(self):
         for g in self.main_grad.values():
@@ -442,7 +466,6 @@ class Engine:
         tr = self.trainable
         dw = self.grad_buffer("model.norm.weight") if "model.norm.weight" in tr else None
         dx = ops.rmsnorm_bwd(d_hn, ctx["x_last"], w["model.norm.weight"], ctx["rstd_f"], dw=dw, out=ws.get("dx_a", (M, d), T))
-        self._notify("model.norm.weight")
         for l in reversed(range(L)):
             p = f"model.layers.{l}."
             lc = ctx["layers"][l]
@@ -484,9 +507,7 @@ class Engine:
             n1 = p + "input_layernorm.weight"
             dx = ops.rmsnorm_bwd(d_h, lc["x_in"], w[n1], lc["rstd1"], dx_add=d_mid,
                                  dw=self.grad_buffer(n1) if n1 in tr else None, out=ws.get("dx_a", (M, d), T))
-            if self.grad_sync is not None:
-                for nm in self.layer_param_names(l):
-                    self._notify(nm)
+            self._notify_layer(l)
         # ---- embedding + splice + projector (pointllm.py:107,126-129,155)
         Pn = pb.point_token_len
         V = lm.vocab_size
@@ -513,11 +534,13 @@ class Engine:
                         for nm in self.trainable:
                             if nm.startswith("model.point_backbone."):
                                 self._notify(nm)
-        if self.grad_sync is not None:
+        if self.grad_sync is not None:                         # everything outside the decoder layers: one last bucket
             self._notify(emb_name)
+            self._notify("model.norm.weight")
             for j in range(len(pb.projection_hidden_dim) + 1):
                 self._notify(f"model.point_proj.{2 * j}.weight")
                 self._notify(f"model.point_proj.{2 * j}.bias")
+            self.grad_sync.flush()
         self.ctx = None
 
     def layer_param_names(self, l):
@@ -535,13 +558,17 @@ class Engine:
             if self.lm_wT is None or self.lm_wT.shape != (d, Vp):
                 self.lm_wT = torch.zeros(d, Vp, dtype=self.dtype, device=self.device)
                 self.lm_wT_stale = True
-            if self.lm_wT_stale or self.lm_wT_ver != (W.data_ptr(), W._version):     # EgoAdamW flags it; torch optimizers bump _version
+            ver = (W.data_ptr(), self.param_ref["lm_head.weight"]._version if "lm_head.weight" in self.param_ref else W._version)
+            if self.lm_wT_stale or self.lm_wT_ver != ver:     # EgoAdamW and load_state_dict flag it; torch optimizers bump the Parameter's _version
                 ops.transpose(W, ldo=Vp, out=self.lm_wT)
-                self.lm_wT_stale, self.lm_wT_ver = False, (W.data_ptr(), W._version)
+                self.lm_wT_stale, self.lm_wT_ver = False, ver
             d_hn = ops.mm(torch.as_strided(d_logits, (d_logits.shape[0], Vp), (Vp, 1)), self.lm_wT,
                           out=self.ws.get("d_hn", hn.shape, self.dtype))
         else:
             d_hn = ops.mm(d_logits, W, out=self.ws.get("d_hn", hn.shape, self.dtype), b_layout=1)
         self._wgrad("lm_head.weight", d_logits, hn)
-        self._notify("lm_head.weight")
+        if self.grad_sync is not None:
+            self.grad_sync.begin_step()
+            self._notify("lm_head.weight")                       # first bucket of the step: travels under the whole backward
+            self.grad_sync.flush()
         return d_hn

@@ -351,6 +351,13 @@ def cast(x, dtype, out=None):
     return out
 
 
+def rank_sum(chunks, out):
+    """chunks [W, c] (bf16 / fp32, contiguous) -> out [c] (bf16 / fp32): fp32-accumulated sum over the leading (rank) axis."""
+    W, c = chunks.shape
+    call("egomi_rank_sum", P(chunks), c_i(dt(chunks.dtype)), c_i(W), c_i64(c), P(out), c_i(dt(out.dtype)), S())
+    return out
+
+
 def add(a, b, out=None):
     out = torch.empty_like(a) if out is None else out
     call("egomi_add", P(a), P(b), P(out), c_i64(a.numel()), c_i(dt(a.dtype)), S())

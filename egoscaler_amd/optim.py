@@ -54,7 +54,11 @@ class EgoAdamW:
                 self.state[n][k].copy_(s[k])
 
 
-def linear_warmup_lr(base_lr, step, total_steps):
-    """train.py:113-117: linear warm-up over the first fifth of the steps, then constant."""
-    warm = max(1, total_steps // 5)
-    return base_lr * min(1.0, (step + 1) / warm)
+def linear_warmup_lr(base_lr, step, total_steps, warmup_steps=None):
+    """HF `get_linear_schedule_with_warmup` as the reference sets it up (train.py:113-116): warm-up over
+    int(total/5) steps starting from lr = 0 at step 0 (`step / warm`), then a linear decay that reaches 0 at
+    `total_steps`.  `step` is the number of optimizer steps already taken (LambdaLR's epoch counter)."""
+    warm = int(total_steps / 5) if warmup_steps is None else int(warmup_steps)
+    if step < warm:
+        return base_lr * float(step) / float(max(1, warm))
+    return base_lr * max(0.0, float(total_steps - step) / float(max(1, total_steps - warm)))

@@ -174,6 +174,7 @@ class TrajPointLLMForCausalLM(nn.Module):
         dev = self.model.embed_tokens.weight.device
         old = self.engine
         self.engine = Engine(self.dims, {k: v.data for k, v in tensors.items()}, dev, dtype)
+        self.engine.param_ref = dict(self.named_parameters())
         if old is not None:
             self.engine.trainable = old.trainable
         pb = self.dims.pb
@@ -197,6 +198,7 @@ class TrajPointLLMForCausalLM(nn.Module):
     def load_state_dict(self, sd, strict=True, **kw):
         r = super().load_state_dict(sd, strict=strict, **kw)
         self.engine.prepared = False
+        self.engine.lm_wT_stale = True          # the padded lm_head transpose follows the loaded values
         return r
 
     def load_pretrained_weights(self):
@@ -263,7 +265,7 @@ class TrajPointLLMForCausalLM(nn.Module):
         self.engine = None
         self._build_engine()
         self.engine.trainable = tr
-        self.engine.main_grad = {}
+        self.engine.main_grad, self.engine.layer_flat = {}, {}
 
     def initialize_tokenizer_point_backbone_config_wo_embedding(self, tokenizer):
         """pointllm.py:277-300."""
@@ -286,13 +288,16 @@ class TrajPointLLMForCausalLM(nn.Module):
         self.point_backbone_config.update(point_patch_token=int(patch), point_start_token=int(start), point_end_token=int(end))
 
     # -- gradients ----------------------------------------------------------------------------------
-    def _begin_backward(self):
+    def _begin_backward(self, explicit=False):
+        """explicit=True (loss_and_backward): gradients are overwritten unless `accumulate_grads` is set, for both dtypes.
+        explicit=False (torch autograd driving `_LogitsFn`): fp32 follows torch semantics (`p.grad is None` after
+        `optimizer.zero_grad()` means fresh, otherwise accumulate); bf16 has no `.grad` and follows `accumulate_grads`."""
         eng = self.engine
         eng._xt_last.clear()                 # transposed-activation cache of engine._wgrad is valid within one backward only
         for n, p in self.named_parameters():
             if n in eng.trainable:
                 g = eng.grad_buffer(n)
-                fresh = (p.grad is None) if p.dtype == torch.float32 else (not self.accumulate_grads)
+                fresh = (p.grad is None) if (p.dtype == torch.float32 and not explicit) else (not self.accumulate_grads)
                 if fresh:
                     if eng.lazy_zero_ok(n):
                         eng.grad_fresh.add(n)          # overwritten by its first wgrad product (engine._wgrad)
@@ -345,7 +350,7 @@ class TrajPointLLMForCausalLM(nn.Module):
         ls, cnt = ops.cross_entropy(lg, tg, pad_token_id, dlogits=lg if backward else None, grad_scale=grad_scale)
         loss = ls / cnt.float()
         if backward:
-            self._begin_backward()
+            self._begin_backward(explicit=True)
             d_hs = eng.backward_logits(lg, hs)
             d_hn = eng.ws.get("d_hn_full", (B, S, d), eng.dtype, zero=True)
             d_hn[:, Lp - 1:S - 1] = d_hs.view(B, S - Lp, d)

@@ -190,3 +190,78 @@ def anglar_distance(gen_rot, gt_rot) -> float:
         d = np.dot(R.from_rotvec(a).as_quat(), R.from_rotvec(b).as_quat())
         ad.append(2 * np.arccos(np.clip(d, -1.0, 1.0)))
     return sum(ad) / len(ad)
+
+
+class TargetNorm:
+    """Target normalisation of CustomDataset (models/pointllm/dataset.py:41-148): `--do_norm` (workspace bounds,
+    rotations / pi) or `--do_standard` (dataset mean / std, then a per-sample max-abs scale so values land in [-1, 1]),
+    with the statistics side file `norm_param.json` {"mean", "std"} (dataset.py:104-124).
+
+    `denorm` is the reference's (dataset.py:126-148).  The forward direction lives in the reference's missing
+    `__getitem__`; it is restated here as the exact inverse of `denorm`:
+      do_norm     : x,y,z -> 2*(v - min)/(max - min) - 1 ; rotvec -> r / pi ;            max_abs = 1
+      do_standard : z = (v - mean) / std ; max_abs[d] = max_t |z[t,d]| ; v_norm = z / max_abs
+    mode "none" (neither flag; the reference's denorm then returns None): values are taken as already normalised."""
+
+    def __init__(self, do_norm=False, do_standard=False, mean=None, std=None):
+        assert not (do_norm and do_standard), "Cannot enable both normalization methods."            # dataset.py:44
+        self.mode = "norm" if do_norm else ("standard" if do_standard else "none")
+        self.mean = None if mean is None else np.asarray(mean, dtype=np.float64)
+        self.std = None if std is None else np.asarray(std, dtype=np.float64)
+
+    # -- statistics (dataset.py:80-124)
+    def fit(self, trajs, num_steps, smooth=False):
+        """compute_mean_std (dataset.py:80-102): every trajectory resampled to num_steps (optionally smoothed), mean and
+        std over (sample, step), std + 1e-8."""
+        allt = []
+        for t in trajs:
+            t = preprocess_traj(np.asarray(t), num_steps)
+            if smooth:
+                t = smoothing_traj(t)
+            allt.append(t)
+        allt = np.array(allt)
+        self.mean, self.std = allt.mean(axis=(0, 1)), allt.std(axis=(0, 1)) + 1e-8
+        return self.mean, self.std
+
+    def save(self, save_dir):
+        import json
+        import os
+        with open(os.path.join(save_dir, "norm_param.json"), "w") as f:
+            json.dump({"mean": self.mean.tolist(), "std": self.std.tolist()}, f)
+
+    def load(self, save_dir):
+        import json
+        import os
+        with open(os.path.join(save_dir, "norm_param.json")) as f:
+            p = json.load(f)
+        self.mean, self.std = np.array(p["mean"]), np.array(p["std"])
+        return self
+
+    # -- per sample
+    def normalize(self, traj):
+        """traj [T,6] (metres, rotation vectors) -> (values in [-1,1] [T,6] float64, max_abs [6])."""
+        t = np.array(traj, dtype=np.float64, copy=True)
+        if self.mode == "norm":
+            for c, k in enumerate("xyz"):
+                lo, hi = WORKSPACE["min_" + k], WORKSPACE["max_" + k]
+                t[:, c] = 2.0 * (t[:, c] - lo) / (hi - lo) - 1.0
+            t[:, 3:6] /= np.pi
+            return t, np.ones(6)
+        if self.mode == "standard":
+            if self.mean is None:
+                raise ValueError("do_standard needs statistics: fit() on the train split or load() norm_param.json")
+            z = (t - self.mean) / self.std
+            m = np.abs(z).max(axis=0)
+            m = np.where(m > 0, m, 1.0)
+            return z / m, m
+        return t, np.ones(6)
+
+    def denorm(self, traj, max_abs):
+        """dataset.py:126-148.  traj [B,T,6] (numpy, copied), max_abs [B,6]."""
+        t = np.array(traj, copy=True)
+        if self.mode == "norm":
+            return denorm(t)
+        if self.mode == "standard":
+            t = t * np.asarray(max_abs)[:, None, :]
+            return t * self.std + self.mean
+        return t

@@ -303,6 +303,11 @@ int egomi_adamw(float* master, void* model_copy, const float* grad, float* m, fl
 int egomi_transpose(const void* in, int R, int C, int64_t ldi, void* out, int64_t ldo, int dtype, egomi_stream_t stream);
 int egomi_cast(const void* in, int in_dtype, void* out, int out_dtype, int64_t n, egomi_stream_t stream);
 int egomi_add(const void* a, const void* b, void* out, int64_t n, int dtype, egomi_stream_t stream);
+/* Gradient exchange of the data-parallel step (replaces DeepSpeed's bucketed gradient reduction behind
+ * model_engine.backward/step, train.py:92-125,183-184): the reduce half of a direct reduce-scatter.  in [W, c] holds the
+ * chunk each of the W ranks sent to this one (all-to-all over xGMI, bf16 on the wire); out [c] = their sum accumulated in
+ * fp32 in rank order.  c % 8 == 0, pointers 16-B aligned.  (in,out) dtypes: (bf16,bf16) (bf16,f32) (f32,f32). */
+int egomi_rank_sum(const void* in, int in_dtype, int W, int64_t c, void* out, int out_dtype, egomi_stream_t stream);
 /* out[c] (fp32, caller-initialised) += sum_r x[r,c]: bias gradients (backward of nn.Linear bias, model/pointllm.py:67-81) */
 int egomi_colsum(const void* x, int64_t R, int C, int64_t ld, float* out, int dtype, egomi_stream_t stream);
 

@@ -225,6 +225,54 @@ def gen_traj():
 
 
 # -------------------------------------------------------------------------------------------------
+def gen_collate():
+    """N1/N2 glue pinned by the reference's own methods: CustomDataset.collate_fn (dataset.py:150-194) and
+    CustomDataset.denorm (dataset.py:126-148), compiled from the reference file with `ast` (the class itself cannot be
+    imported: deepspeed-free but it needs tqdm/egoscaler package imports that pull missing deps) and called on a stand-in
+    `self` that carries exactly the attributes the two methods read."""
+    from egoscaler.configs import DatasetConfig
+    path = os.path.join(REF, "egoscaler/models/pointllm/dataset.py")
+    collate = _method_from(path, "CustomDataset", "collate_fn", {"torch": torch, "np": np})
+    denorm = _method_from(path, "CustomDataset", "denorm", {"torch": torch, "np": np, "dataset_cfg": DatasetConfig})
+    g = np.random.default_rng(5)
+    B, Ld, Lt, T = 3, 9, 21, 2
+    SEP, TSEP = [11, 12, 13], 90
+    desc = g.integers(20, 80, (B, Ld))
+    dmask = np.ones((B, Ld), dtype=bool)
+    dmask[1, 6:] = False
+    dmask[2, 4:] = False
+    traj_tok = g.integers(100, 116, (B, Lt))
+    traj_tok[:, 0] = 89
+    traj_tok[:, 7] = TSEP
+    traj_tok[:, 14] = TSEP
+    tmask = np.ones((B, Lt), dtype=bool)
+    tmask[0, 17:] = False
+    gt = g.normal(size=(B, T, 6)).astype(np.float32)
+    gtm = np.ones((B, T), dtype=bool)
+    mabs = g.uniform(0.5, 2.0, (B, 6))
+    batch = [(torch.tensor(100 + b), torch.from_numpy(g.normal(size=(16, 6)).astype(np.float32)), desc[b].tolist(), dmask[b].tolist(),
+              traj_tok[b].tolist(), tmask[b].tolist(), torch.from_numpy(gt[b]), torch.from_numpy(gtm[b]), mabs[b]) for b in range(B)]
+    me = types.SimpleNamespace(sep_token_id=torch.tensor([SEP]), time_sep_token_id=torch.tensor([[TSEP]]))
+    out = collate(me, batch)
+    res = {"desc": desc, "desc_mask": dmask, "traj_tok": traj_tok, "traj_mask": tmask, "gt": gt, "max_abs": mabs,
+           "sep_ids": np.array(SEP), "tsep": np.array(TSEP), "pcrgbs": torch.stack([b[1] for b in batch]).numpy()}
+    for k, v in out.items():
+        res["out:" + k] = v.numpy()
+    # denorm, both branches
+    x = g.uniform(-1, 1, (B, 5, 6)).astype(np.float32)
+    me_n = types.SimpleNamespace(do_norm=True, do_standard=False)
+    res["denorm_in"] = x
+    res["denorm_norm"] = denorm(me_n, torch.from_numpy(x.copy()), mabs)
+    mean, std = g.normal(size=6), g.uniform(0.1, 1.0, 6)
+    me_s = types.SimpleNamespace(do_norm=False, do_standard=True, mean=mean, std=std)
+    res["denorm_standard"] = denorm(me_s, torch.from_numpy(x.copy()), mabs)
+    res["mean"], res["std"] = mean, std
+    assert denorm(types.SimpleNamespace(do_norm=False, do_standard=False), torch.from_numpy(x.copy()), mabs) is None
+    np.savez_compressed(os.path.join(GOLD, "collate.npz"), **res)
+    print("collate.npz: reference collate_fn + denorm recorded;", {k: v.shape for k, v in out.items()})
+
+
+# -------------------------------------------------------------------------------------------------
 def _pb_cfg(pb: PointBertDims):
     from easydict import EasyDict
     return EasyDict(model=dict(NAME="PointTransformer", trans_dim=pb.trans_dim, depth=pb.depth, drop_path_rate=getattr(pb, "drop_path_rate", 0.1),
@@ -481,8 +529,178 @@ def gen_tiny_pc_unfrozen():
     RPL.cfg_from_yaml_file = orig_cfg
 
 
+def gen_tiny_model_bf16():
+    """The reference's TRAINING numerics: bf16 weights (DeepSpeed `bf16: enabled`, train.py:97-98) under
+    autocast(bfloat16) (train.py:166) — run here on the CPU (`torch.autocast("cpu", torch.bfloat16)`), same tiny model,
+    weights and batch as tiny_model.npz.  Records loss / logits / gradients, plus their distance from the fp32 golden so
+    that the GPU bf16 tests can bound their own error by a multiple of the reference's own bf16 error."""
+    import pointllm.model.pointllm as RPL
+    from pointllm.model import PointLLMLlamaForCausalLM, PointLLMConfig
+    import model_arch as RMA
+    dims = dims_tiny()
+    lm, pb, tok = dims.lm, dims.pb, dims.tok
+    orig_cfg = RPL.cfg_from_yaml_file
+    RPL.cfg_from_yaml_file = lambda path: _pb_cfg(pb) if os.path.basename(path) == "tiny.yaml" else orig_cfg(path)
+    cfg = PointLLMConfig(hidden_size=lm.hidden_size, intermediate_size=lm.intermediate_size,
+                         num_hidden_layers=lm.num_hidden_layers, num_attention_heads=lm.num_attention_heads,
+                         num_key_value_heads=lm.num_attention_heads, vocab_size=lm.vocab_size,
+                         rms_norm_eps=lm.rms_norm_eps, max_position_embeddings=lm.max_position_embeddings,
+                         pad_token_id=tok.pad, bos_token_id=tok.bos, eos_token_id=tok.eos,
+                         point_backbone="PointBERT", point_backbone_config_name="tiny", use_color=True,
+                         mm_use_point_start_end=True, DEFAULT_POINT_PATCH_TOKEN="<point_patch>",
+                         DEFAULT_POINT_START_TOKEN="<point_start>", DEFAULT_POINT_END_TOKEN="<point_end>",
+                         tie_word_embeddings=False, attn_implementation="eager")
+    base = PointLLMLlamaForCausalLM(cfg)
+    sd = synth.synth_state_dict(dims, 0)
+    base.load_state_dict(sd, strict=True)
+    tmp = tempfile.mkdtemp()
+    base.save_pretrained(tmp)
+    B = 2
+    toks, masks, Lp = synth.synth_batch(dims, B, text_len=8, num_steps=4, max_traj_token=40)
+    pts = torch.stack([synth.synth_cloud(dims, i) for i in range(B)])
+    start = np.array([0, 17])
+    g32 = np.load(os.path.join(GOLD, "tiny_model.npz"), allow_pickle=False)
+    out = {"fps_start": start}
+    for tag, unfreeze in (("unfrozen", True), ("frozen", False)):
+        args = types.SimpleNamespace(unfreeze_pc_encoder=False, unfreeze_language_model=unfreeze, model_name=tmp, num_bins=tok.num_bins)
+        model = RMA.TrajPointLLMForCausalLM(args, cfg, tmp)
+        model.load_state_dict(sd, strict=True)
+        model.get_model().point_backbone_config.update(point_patch_token=tok.point_patch, point_start_token=tok.point_start, point_end_token=tok.point_end)
+        model = model.to(torch.bfloat16)                                     # DeepSpeed bf16 engine: parameters live in bf16
+        model.train()
+        with fixed_fps_start(start), torch.autocast("cpu", dtype=torch.bfloat16):
+            o = model(input_ids=toks, attention_mask=masks, point_clouds=pts, return_dict=True)
+        logits = o.logits
+        lg = logits[:, Lp - 1:-1, :]
+        loss = F.cross_entropy(lg.reshape(-1, lg.shape[-1]), toks[:, Lp:].flatten(), ignore_index=tok.pad)        # train.py:174-181 (outside autocast)
+        loss.backward()
+        grads = {n: p.grad.detach().float() for n, p in model.named_parameters() if p.grad is not None}
+        out[f"{tag}:loss"] = np.array(float(loss))
+        out[f"{tag}:logits"] = logits.detach().float().numpy()
+        out[f"{tag}:logits_dtype"] = np.array(str(logits.dtype))
+        for k in g32.files:
+            if k.startswith("grad:") and k[5:] in grads:
+                out[f"{tag}:{k}"] = grads[k[5:]].numpy()
+                out[f"{tag}:relerr_vs_fp32:{k[5:]}"] = np.array(rel(grads[k[5:]].numpy(), g32[k]))
+        out[f"{tag}:loss_relerr_vs_fp32"] = np.array(abs(float(loss) - float(g32["loss"])) / abs(float(g32["loss"])))
+        out[f"{tag}:logits_relerr_vs_fp32"] = np.array(rel(out[f"{tag}:logits"], g32["logits"]))
+        worst = max(float(out[k]) for k in out if k.startswith(f"{tag}:relerr_vs_fp32:"))
+        print(f"tiny_model_bf16[{tag}]: loss {float(loss):.5f} (fp32 {float(g32['loss']):.5f}), logits rel vs fp32 {float(out[f'{tag}:logits_relerr_vs_fp32']):.3e}, "
+              f"worst grad rel vs fp32 {worst:.3e}, logits dtype {logits.dtype}")
+    np.savez_compressed(os.path.join(GOLD, "tiny_model_bf16.npz"), **out)
+    RPL.cfg_from_yaml_file = orig_cfg
+
+
+def gen_tiny_trained():
+    """End-to-end "6DoF ADE vs ref" chain (BASELINE metric's second half; train.py:240-260, evaluate.py:128-146):
+    the reference tiny model is TRAINED here for a few hundred AdamW steps on two synthetic samples (its own forward /
+    loss / backward, torch.optim.AdamW as train.py:107-111) until greedy decoding emits well-formed trajectories; recorded:
+    the trained weights, the reference's greedy token ids, the trajectory the reference's own `str_to_float` parses out of
+    them, and ADE / FDE from the reference's metrics.py in both the documented and the as-called form."""
+    import pointllm.model.pointllm as RPL
+    from pointllm.model import PointLLMLlamaForCausalLM, PointLLMConfig
+    import model_arch as RMA
+    from egoscaler.models.utils import metrics as RM
+    from egoscaler.configs.camera import CameraConfig
+    glb = {"np": np, "re": __import__("re"), "PINHOLE_IMAGE_HEIGHT": 1408, "PINHOLE_IMAGE_WIDTH": 1408,
+           "FOCAL_LEN": CameraConfig.devices.aria.focal_len, "PRICIPAL_POINT": CameraConfig.devices.aria.principal_point}
+    names = ["discretize_action", "token_to_action", "rt2_scaler", "str_to_float"]
+    fns = _functions_from(os.path.join(REF, "egoscaler/models/pointllm/utils/utils.py"), names, glb)
+    for f_ in fns:
+        f_.__globals__.update({n: fn for n, fn in zip(names, fns)})
+    s2f = fns[3]
+    dims = dims_tiny()
+    lm, pb, tok = dims.lm, dims.pb, dims.tok
+    orig_cfg = RPL.cfg_from_yaml_file
+    RPL.cfg_from_yaml_file = lambda path: _pb_cfg(pb) if os.path.basename(path) == "tiny.yaml" else orig_cfg(path)
+    cfg = PointLLMConfig(hidden_size=lm.hidden_size, intermediate_size=lm.intermediate_size,
+                         num_hidden_layers=lm.num_hidden_layers, num_attention_heads=lm.num_attention_heads,
+                         num_key_value_heads=lm.num_attention_heads, vocab_size=lm.vocab_size,
+                         rms_norm_eps=lm.rms_norm_eps, max_position_embeddings=lm.max_position_embeddings,
+                         pad_token_id=tok.pad, bos_token_id=tok.bos, eos_token_id=tok.eos,
+                         point_backbone="PointBERT", point_backbone_config_name="tiny", use_color=True,
+                         mm_use_point_start_end=True, DEFAULT_POINT_PATCH_TOKEN="<point_patch>",
+                         DEFAULT_POINT_START_TOKEN="<point_start>", DEFAULT_POINT_END_TOKEN="<point_end>",
+                         tie_word_embeddings=False, attn_implementation="eager")
+    base = PointLLMLlamaForCausalLM(cfg)
+    sd = synth.synth_state_dict(dims, 0)
+    base.load_state_dict(sd, strict=True)
+    tmp = tempfile.mkdtemp()
+    base.save_pretrained(tmp)
+    args = types.SimpleNamespace(unfreeze_pc_encoder=False, unfreeze_language_model=True, model_name=tmp, num_bins=tok.num_bins)
+    model = RMA.TrajPointLLMForCausalLM(args, cfg, tmp)
+    model.load_state_dict(sd, strict=True)
+    model.get_model().point_backbone_config.update(point_patch_token=tok.point_patch, point_start_token=tok.point_start, point_end_token=tok.point_end)
+    B = 2
+    toks, masks, Lp = synth.synth_batch(dims, B, text_len=8, num_steps=4, max_traj_token=40)
+    pts = torch.stack([synth.synth_cloud(dims, i) for i in range(B)])
+    start = np.array([0, 17])
+    opt = torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=2e-3)
+    model.train()
+    STOP = float(os.environ.get("TINY_TRAINED_STOP", "0.5"))           # early stop: well-formed but imperfect generations (ADE > 0)
+    for it in range(400):
+        opt.zero_grad()
+        with fixed_fps_start(start):
+            lg = model(input_ids=toks, attention_mask=masks, point_clouds=pts, return_dict=True).logits[:, Lp - 1:-1, :]
+        loss = F.cross_entropy(lg.reshape(-1, lg.shape[-1]), toks[:, Lp:].flatten(), ignore_index=tok.pad)
+        loss.backward()
+        opt.step()
+        if it % 50 == 0 or float(loss) < STOP:
+            print(f"   tiny_trained step {it}: loss {float(loss):.4f}")
+        if float(loss) < STOP:
+            break
+    model.eval()
+    n_new = int(masks[0].sum()) - Lp                                  # up to and including eos
+    prompts, pmask = toks[:, :Lp], masks[:, :Lp]
+    seq, msk = prompts, pmask
+    for t in range(n_new):
+        with fixed_fps_start(start), torch.no_grad():
+            lg_t = model(input_ids=seq, attention_mask=msk, point_clouds=pts, return_dict=True).logits[:, -1, :]
+        seq = torch.cat([seq, lg_t.argmax(-1, keepdim=True)], 1)
+        msk = torch.cat([msk, torch.ones_like(msk[:, :1])], 1)
+    trained = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    so, _ = OPL.greedy_generate(trained, dims, prompts, pmask, pts, start, n_new)
+    print("   greedy ids: oracle == reference", bool(torch.equal(so, seq)), "; reproduces the training targets:", bool(torch.equal(seq, toks[:, :Lp + n_new])))
+
+    def ids_to_string(ids):                       # tokenizer.decode of added (non-special) tokens: joined by single spaces; cut at eos (train.py:241-244)
+        ids = ids.tolist()
+        if tok.eos in ids:
+            ids = ids[:ids.index(tok.eos)]
+        w = []
+        for i in ids:
+            if tok.p0 <= i < tok.p0 + tok.num_bins:
+                w.append(f"<p{i - tok.p0}>")
+            elif i in (tok.ts, tok.tsep, tok.te):
+                w.append({tok.ts: "<ts>", tok.tsep: "<tsep>", tok.te: "<te>"}[i])
+            else:
+                w.append(f"<unk{i}>")
+        return " ".join(w)
+    out = {"tokens": toks.numpy(), "masks": masks.numpy(), "prompt_len": np.array(Lp), "fps_start": start, "n_new": np.array(n_new),
+           "gen_sequences": seq.numpy()}
+    maxmin = [2.5, 0.1]
+    for b in range(B):
+        # the prompt ends with the first step + <tsep> (dataset.py:180-182): the drivers parse only the generated span
+        gen_s, gt_s = ids_to_string(seq[b, Lp:]), ids_to_string(toks[b, Lp:])
+        gen = s2f(gen_s, maxmin, "val", rt2=True, num_bins=tok.num_bins)
+        gt = s2f(gt_s, maxmin, "val", rt2=True, num_bins=tok.num_bins)
+        # a deliberately shorter generation exercises the pad-with-last-step rule (train.py:252-256)
+        short = gen[:-1]
+        pad = np.concatenate([short, np.repeat(short[-1][None, :], gt.shape[0] - short.shape[0], axis=0)], 0)
+        out[f"gen_string{b}"] = np.array(gen_s)
+        out[f"gen_traj{b}"], out[f"gt_traj{b}"] = gen, gt
+        out[f"ade_as_called{b}"] = np.array(RM.average_displacement_error(gen[None], gt[None]))
+        out[f"ade{b}"] = np.array(RM.average_displacement_error(gen, gt))
+        out[f"fde{b}"] = np.array(RM.final_displacement_error(gen, gt))
+        out[f"ade_short_padded{b}"] = np.array(RM.average_displacement_error(pad, gt))
+        print(f"   sample {b}: steps {gen.shape[0]} (gt {gt.shape[0]}), ADE {float(out[f'ade{b}']):.6f}, as called {float(out[f'ade_as_called{b}']):.6f}")
+    for k, v in trained.items():
+        out["w:" + k] = v.numpy()
+    np.savez_compressed(os.path.join(GOLD, "tiny_trained.npz"), **out)
+    RPL.cfg_from_yaml_file = orig_cfg
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["pointcloud", "depth_cloud", "traj", "pointbert_full", "tiny_model", "tiny_pc_unfrozen"]
+    which = sys.argv[1:] or ["pointcloud", "depth_cloud", "traj", "collate", "pointbert_full", "tiny_model", "tiny_pc_unfrozen", "tiny_model_bf16", "tiny_trained"]
     for w in which:
         globals()["gen_" + w]()
     sizes = {f: os.path.getsize(os.path.join(GOLD, f)) for f in sorted(os.listdir(GOLD))}

@@ -26,22 +26,34 @@ def _worker(rank, world, port, q):
     try:
         lo, hi = shard_range(8, rank, world)
         sync = GradSync()
-        # "gradients" whose value depends on the rank's shard; ready() in backward order
+        # "gradients" whose value depends on the rank's shard; ready() in backward order, packed into ONE bucket
         bufs = {n: torch.full((5, 3), float(sum(range(lo, hi)) + i), dtype=torch.float32) for i, n in enumerate(["lm_head", "norm", "embed"])}
         for n in ["lm_head", "norm", "embed"]:
             sync.ready(n, bufs[n])
         sync.finish()
-        # bf16 wire for large fp32 buffers: same sums (these values are exact in bf16), half the bytes, small ones untouched
+        st1 = dict(sync.stats)
+        # bf16 wire with fp32 accumulation: a flat "layer" block, a packed bucket of loose tensors, a small fp32 bucket
         s2 = GradSync(wire_dtype=torch.bfloat16, wire_min_bytes=1024)
-        big = torch.full((64, 16), float(rank + 1) * 0.5, dtype=torch.float32)
-        small = torch.full((4,), float(rank + 1), dtype=torch.float32)
+        s2.begin_step()
+        layer = torch.full((1000,), float(rank + 1) * 0.5, dtype=torch.float32)             # 1000 is not a multiple of world*8: padded chunks
+        s2.ready_flat("layer0", layer)
         noisy = torch.arange(1024, dtype=torch.float32) * (1.0 + 1e-3 * rank) + 0.123
-        s2.ready("big", big); s2.ready("small", small); s2.ready("noisy", noisy)
+        big = torch.full((64, 16), float(rank + 1) * 0.25, dtype=torch.float32)
+        s2.ready("noisy", noisy); s2.ready("big", big)
+        s2.flush()
+        small = torch.full((4,), float(rank + 1), dtype=torch.float32)
+        s2.ready("small", small)
         s2.finish()
-        exact = sum(torch.arange(1024, dtype=torch.float32) * (1.0 + 1e-3 * r) + 0.123 for r in range(world))
-        wire_ok = bool(torch.equal(big, torch.full((64, 16), 1.5)) and torch.equal(small, torch.full((4,), 3.0))
-                       and big.dtype == torch.float32 and float(((noisy - exact).abs() / exact.abs()).max()) < 2 ** -6)
-        q.put((rank, lo, hi, {n: float(b[0, 0]) for n, b in bufs.items()}, sync.grad_scale, sync.bytes, wire_ok, s2.bytes, noisy.clone()))
+        # what "bf16 on the wire, fp32 accumulate" must give: every contribution rounded to bf16 once, summed in fp32 in rank
+        # order, the sum rounded to bf16 once for the gather
+        contrib = [(torch.arange(1024, dtype=torch.float32) * (1.0 + 1e-3 * r) + 0.123).bfloat16().float() for r in range(world)]
+        acc = contrib[0].clone()
+        for c in contrib[1:]:
+            acc += c
+        want_noisy = acc.bfloat16().float()
+        wire_ok = bool(torch.equal(layer, torch.full((1000,), 1.5)) and torch.equal(big, torch.full((64, 16), 0.75))
+                       and torch.equal(small, torch.full((4,), 3.0)) and big.dtype == torch.float32 and torch.equal(noisy, want_noisy))
+        q.put((rank, lo, hi, {n: float(b[0, 0]) for n, b in bufs.items()}, sync.grad_scale, st1, wire_ok, dict(s2.stats), noisy.clone()))
     finally:
         dist.destroy_process_group()
 
@@ -62,8 +74,9 @@ def test_grad_sync_world2_gloo():
     total = sum(range(8))
     for r in res:
         assert r[3] == {"lm_head": total + 0.0, "norm": total + 2.0, "embed": total + 4.0}   # summed over ranks
-        assert r[4] == 0.5 and r[5] == 3 * 5 * 3 * 4
-        assert r[6] and r[7] == 64 * 16 * 2 + 4 * 4 + 1024 * 2          # big and noisy travel as bf16, small stays fp32
+        assert r[4] == 0.5 and r[5]["buckets"] == 1 and r[5]["collective_calls"] == 1          # three tensors, one fp32 all-reduce
+        assert r[6], "bf16-wire buckets must equal the fp32-accumulated sum of bf16-rounded contributions"
+        assert r[7]["buckets"] == 3 and r[7]["collective_calls"] == 2 + 2 + 1                  # wire buckets: all-to-all + all-gather
     assert torch.equal(res[0][8], res[1][8])                             # replicas hold identical reduced values
 
 
@@ -79,6 +92,8 @@ def test_shard_range_and_single_process():
 
 
 def test_linear_warmup_schedule():
+    """train.py:113-116: warm-up from 0 over int(total/5) steps, then linear decay to 0 (pinned against HF's own
+    scheduler in tests/test_host_glue.py)."""
     from egoscaler_amd.optim import linear_warmup_lr
-    lrs = [linear_warmup_lr(2e-5, s, 100) for s in range(100)]
-    assert abs(lrs[0] - 1e-6) < 1e-12 and abs(lrs[19] - 2e-5) < 1e-12 and lrs[50] == 2e-5
+    lrs = [linear_warmup_lr(2e-5, s, 100) for s in range(101)]
+    assert lrs[0] == 0.0 and abs(lrs[10] - 1e-5) < 1e-12 and abs(lrs[20] - 2e-5) < 1e-12 and abs(lrs[60] - 1e-5) < 1e-12 and lrs[100] == 0.0

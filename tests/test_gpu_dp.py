@@ -67,7 +67,7 @@ def _worker(rank, world, port, wire, q):
         grads = {n: (m.engine.main_grad[n] * sync.grad_scale).float().cpu().numpy() for n in names}      # numpy: pickled by value
         opt.step(grad_scale=sync.grad_scale)
         w = {n: dict(m.named_parameters())[n].detach().float().cpu().numpy() for n in names}
-        q.put((rank, float(loss), grads, w, sync.bytes))
+        q.put((rank, float(loss), grads, w, dict(sync.stats)))
     finally:
         dist.destroy_process_group()
 
@@ -98,5 +98,8 @@ def test_two_ranks_match_single_process_full_batch(wire):
         assert float(np.abs(g0 - ref).max()) <= tol, n                                         # DP mean gradient == full-batch gradient
         assert np.array_equal(g0, res[1][2][n]), n                                            # both ranks hold the same reduced gradient
         assert np.array_equal(res[0][3][n], res[1][3][n]), n                                  # ... and the same weights after the step
+    nparam = sum(p.numel() for n, p in m.named_parameters() if n in m.engine.trainable)
+    st = res[0][4]
+    assert st["buckets"] == 1 + dims.lm.num_hidden_layers + 1, st              # lm_head, one per decoder layer (reverse order), the rest
     if wire:
-        assert res[0][4] < 0.75 * sum(p.numel() * 4 for n, p in m.named_parameters() if n in m.engine.trainable)   # bf16 on the wire
+        assert st["wire_bytes"] < 0.75 * nparam * 4                               # bf16 on the wire (2 phases x (W-1)/W x 2 B)

@@ -1,0 +1,149 @@
+"""GPU parity of the MEASURED path: bf16, LLaMA-7B width (d=4096, ffn=11008, H=32 -> head_dim 128, V=32262), the bench's
+own batch geometry (B=8, S=692 -> M=5536), two decoder layers, frozen and unfrozen — against the CPU oracle evaluated in
+fp32 on the same bf16-rounded weights (train.py:97-98,166-181: the reference trains bf16 weights under autocast).
+
+What this pins that the tiny-dims golden tests cannot reach: `gemm_nt_bf16_8phase_kernel` (needs >=128 256x256 tiles and
+K >= 2048), the stacked [Wq;Wk;Wv] / [Wgate;Wup] weights, the K-concatenated dgrads, the fused head_dim-128 attention with
+the inverse-RoPE epilogue, the padded-V64 lm_head dgrad, and the transposed-operand wgrads of the unfrozen mode.
+
+Tolerances: the comparison is bf16 arithmetic vs fp32 arithmetic, so the floor is bf16 rounding of every
+activation (2^-9 relative per rounding, a few dozen roundings deep).  A layout or indexing bug produces O(1) relative
+error; the bounds below are ~3x what the correct path measures on MI355X (values in the assertion messages).
+"""
+import copy
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from egoscaler_amd import synth
+from egoscaler_amd.config import dims_7b
+
+pytestmark = pytest.mark.gpu
+
+B, TEXT, STEPS, MAXT = 8, 16, 20, 160
+LAYERS = 2
+FRO_TOL = 2.5e-2          # ||got - ref||_F / ||ref||_F
+MAX_TOL = 8e-2            # max|got - ref| / max|ref|
+LOSS_TOL = 5e-3           # relative
+
+
+def _dims():
+    d = dims_7b()
+    d.lm.num_hidden_layers = LAYERS
+    return d
+
+
+def _errs(got, ref):
+    got = got.detach().float().cpu()
+    ref = ref.detach().float().cpu()
+    fro = float((got - ref).norm() / (ref.norm() + 1e-30))
+    mx = float((got - ref).abs().max() / (ref.abs().max() + 1e-30))
+    return fro, mx
+
+
+WATCH_ALWAYS = ["model.embed_tokens.weight", "lm_head.weight", "model.norm.weight",
+                "model.point_proj.0.weight", "model.point_proj.2.weight", "model.point_proj.4.weight", "model.point_proj.4.bias"]
+WATCH_LAYERS = [f"model.layers.{l}.{n}" for l in range(LAYERS) for n in
+                ("self_attn.q_proj.weight", "self_attn.k_proj.weight", "self_attn.v_proj.weight", "self_attn.o_proj.weight",
+                 "mlp.gate_proj.weight", "mlp.up_proj.weight", "mlp.down_proj.weight", "input_layernorm.weight",
+                 "post_attention_layernorm.weight")]
+
+
+@pytest.fixture(scope="module")
+def wide():
+    """Inputs, bf16-rounded weights and the fp32 oracle's loss / hidden / gradients (one CPU pass, every LLM weight trainable:
+    the frozen mode's gradients are a subset of the same numbers)."""
+    from oracle import pointllm as OPL, llama as OL
+    dims = _dims()
+    toks, masks, Lp = synth.synth_batch(dims, B, text_len=TEXT, num_steps=STEPS, max_traj_token=MAXT)
+    pts = torch.stack([synth.synth_cloud(dims, i) for i in range(B)])
+    start = np.arange(B) * 13 % dims.pb.npoints
+    sd = synth.synth_state_dict(dims, 0)
+    sd = {k: (v.to(torch.bfloat16).float() if v.dtype.is_floating_point else v) for k, v in sd.items()}     # what the GPU holds
+    watch = set(WATCH_ALWAYS + WATCH_LAYERS)
+    sdo = {k: (v.clone().requires_grad_(True) if k in watch else v) for k, v in sd.items()}
+    taps = {}
+    torch.set_num_threads(max(1, min(32, torch.get_num_threads())))
+    logits = OPL.forward(sdo, dims, toks, masks, pts, start, taps=taps)
+    loss = OL.traj_loss(logits, toks, Lp, dims.tok.pad)
+    loss.backward()
+    ref = {"loss": float(loss), "hidden": taps["hidden"].detach(), "grads": {k: sdo[k].grad.detach() for k in watch}}
+    del logits, taps, sdo
+    return dims, toks, masks, Lp, pts, start, sd, ref
+
+
+def _model(dims, sd, unfreeze):
+    from egoscaler_amd.pointllm import TrajPointLLMForCausalLM
+    args = types.SimpleNamespace(unfreeze_pc_encoder=False, unfreeze_language_model=unfreeze, num_bins=dims.tok.num_bins, model_name=None)
+    m = TrajPointLLMForCausalLM(args, copy.deepcopy(dims), None, device="cuda", dtype=torch.bfloat16)
+    m.load_state_dict({k: (v.to(torch.bfloat16) if v.dtype.is_floating_point else v) for k, v in sd.items()}, strict=True)
+    return m.train()
+
+
+@pytest.mark.parametrize("unfreeze", [False, True], ids=["frozen_llm", "unfrozen_llm"])
+def test_bf16_7b_width_step_matches_fp32_oracle(wide, unfreeze):
+    from egoscaler_amd import ops
+    dims, toks, masks, Lp, pts, start, sd, ref = wide
+    m = _model(dims, sd, unfreeze)
+    eng = m.engine
+    prof = ops.GemmProfiler(min_flops=0, kernel_ids=(2,))
+    ops.PROFILER = prof
+    try:
+        loss = m.loss_and_backward(toks.cuda(), masks.cuda(), pts.cuda(), Lp, dims.tok.pad, fps_start=start)
+    finally:
+        ops.PROFILER = None
+    torch.cuda.synchronize()
+
+    # ---- the kernels the bench measures were the ones that ran
+    n8 = len(prof.recs)
+    assert n8 >= (8 if not unfreeze else 8) * LAYERS, f"8-phase GEMM launches: {n8}"      # fwd qkv,o,gate|up,down + their dgrads per layer
+    assert eng.use_fused_attention and eng.dtype == torch.bfloat16 and dims.lm.head_dim == 128
+    if not unfreeze:
+        assert sorted(eng.wqkv) == sorted(eng.wgu) == sorted(eng.wqkvT) == sorted(eng.wguT) == list(range(LAYERS))
+        d, f = dims.lm.hidden_size, dims.lm.intermediate_size
+        assert eng.wqkv[0].shape == (3 * d, d) and eng.wqkvT[0].shape == (d, 3 * d) and eng.wgu[0].shape == (2 * f, d) and eng.wguT[0].shape == (d, 2 * f)
+    else:
+        assert not eng.wqkv and not eng.wgu                 # trainable weights are not stacked (their copies would go stale)
+
+    # ---- loss
+    assert abs(float(loss) - ref["loss"]) < LOSS_TOL * abs(ref["loss"]), (float(loss), ref["loss"])
+
+    # ---- gradients
+    names = WATCH_ALWAYS + (WATCH_LAYERS if unfreeze else [])
+    report = {}
+    for n in names:
+        g = eng.main_grad[n]
+        assert g.dtype == torch.float32
+        report[n] = _errs(g, ref["grads"][n])
+    bad = {n: e for n, e in report.items() if e[0] > FRO_TOL or e[1] > MAX_TOL}
+    assert not bad, f"gradient mismatch (fro, max): {bad}\nall: {report}"
+    if not unfreeze:
+        assert not any(n.startswith("model.layers.") for n in eng.main_grad)
+
+    # ---- final hidden state (a forward without saving, same weights)
+    with torch.no_grad():
+        hn = eng.forward_hidden(toks.cuda(), masks.cuda(), pts.cuda(), start, save=False)
+    real = masks.reshape(-1)                                 # padded query rows attend to real keys only; compare the real rows
+    fro, mx = _errs(hn[real.cuda()], ref["hidden"].reshape(-1, hn.shape[1])[real])
+    assert fro < FRO_TOL and mx < MAX_TOL, (fro, mx)
+    print(f"[parity-7b {'unfrozen' if unfreeze else 'frozen'}] loss {float(loss):.5f} vs {ref['loss']:.5f}; hidden fro {fro:.2e} max {mx:.2e}; "
+          + "; ".join(f"{n.replace('model.', '')}: {e[0]:.1e}/{e[1]:.1e}" for n, e in report.items()))
+
+
+def test_bf16_7b_width_frozen_equals_unfrozen_on_shared_gradients(wide):
+    """The stacked / K-concatenated weights of the frozen mode and the per-weight products of the unfrozen mode are two
+    routes to the same dgrad: gradients of the tensors both modes train must agree to bf16 accumulation noise."""
+    dims, toks, masks, Lp, pts, start, sd, ref = wide
+    res = {}
+    for unfreeze in (False, True):
+        m = _model(dims, sd, unfreeze)
+        loss = m.loss_and_backward(toks.cuda(), masks.cuda(), pts.cuda(), Lp, dims.tok.pad, fps_start=start)
+        res[unfreeze] = (float(loss), {n: m.engine.main_grad[n].clone() for n in WATCH_ALWAYS})
+        del m
+        torch.cuda.empty_cache()
+    assert abs(res[False][0] - res[True][0]) < 2e-3 * abs(res[True][0])
+    for n in WATCH_ALWAYS:
+        fro, mx = _errs(res[False][1][n], res[True][1][n])
+        assert fro < 1.5e-2, (n, fro, mx)

@@ -48,27 +48,9 @@ pc = synth.synth_cloud(dims, 0)[None].to(dev)
 dec = Decoder(eng, B, S0 + T)
 # prefill in chunks (the prompt pass is not what config 5 times); each chunk fills its slice of the cache
 t0 = time.perf_counter()
-C = a.prefill_chunk
-for b0 in range(0, B, C):
-    sub = Decoder.__new__(Decoder)
-    sub.eng, sub.B, sub.Smax = eng, C, S0 + T
-    sub.kc, sub.vc = dec.kc[:, b0:b0 + C], dec.vc[:, b0:b0 + C]
-    def sink(l, qkv, Bc, Sq, sub=sub):
-        from egoscaler_amd.decode import kv_append
-        d = eng.dims.lm.hidden_size
-        # slices of the big cache are not contiguous over batch: append sample by sample
-        for i in range(Bc):
-            kv_append(qkv[i * Sq:(i + 1) * Sq, d:2 * d], qkv[i * Sq:(i + 1) * Sq, 2 * d:], qkv.stride(0), sub.kc[l, i], sub.vc[l, i], 1, Sq,
-                      eng.dims.lm.num_attention_heads, eng.dims.lm.head_dim, sub.Smax, 0)
-    hn = eng.forward_hidden(ids[b0:b0 + C], None, pc.repeat(C, 1, 1), torch.zeros(C, dtype=torch.int32, device=dev), save=False, kv_sink=sink)
-    last = hn.view(C, S0, -1)[:, -1].contiguous()
-    dec.lg[b0:b0 + C] = eng.logits(last)
+dec.prefill_chunked(ids, None, pc.repeat(B, 1, 1), torch.zeros(B, dtype=torch.int32, device=dev), T, chunk=a.prefill_chunk)
 torch.cuda.synchronize()
 t_prefill = time.perf_counter() - t0
-dec.mask = torch.ones(B, S0 + T, dtype=torch.uint8, device=dev)
-dec.seq = torch.zeros(B, S0 + T, dtype=torch.int64, device=dev)
-dec.seq[:, :S0] = ids
-dec.pos = S0
 lg_prefill = dec.lg.clone()
 seq, _ = dec.greedy(T, use_graph=True, keep_scores=False)          # capture + first replay
 torch.cuda.synchronize()
