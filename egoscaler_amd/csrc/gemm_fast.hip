@@ -442,6 +442,297 @@ void gemm_nt_bf16_8phase_kernel(FastArgs g) {
 }
 
 
+// =================================================================================================
+// Persistent form of the 8-phase kernel: ONE 512-thread block per CU walks a static list of work items, and the LDS-DMA
+// pipeline never drains between them (the two K-tiles the schedule keeps in flight are simply the next item's first two).
+//   items of block b (G = grid = number of CUs, T = tiles, nt = K-tiles per tile, even):
+//     * full rounds: tile L = j*G + (b&7)*(G/8) + (b>>3) for j < T/G — the 32 blocks that share an XCD (b and b+8 do, as
+//       the dispatcher deals blocks round-robin) take 32 consecutive tiles of the grouped order = 8 M-tiles x 4 N-tiles
+//     * remainder (R = T mod G tiles, fewer than the chip has CUs): stream-K.  Its R*nt/2 K-tile PAIRS are dealt evenly to
+//       the first Gr = min(G, 4R) blocks, contiguous ranges, so a block touches at most two of those tiles and a tile is
+//       shared by <= ~4 blocks.  Each sharer drops its fp32 partial tile as a slab (register-major: 1-KiB wave stores) into
+//       the caller's workspace, publishes it (agent-scope release) and draws a ticket; whoever draws the LAST ticket of
+//       a tile acquires, adds the other slabs to its registers and runs the epilogue.  Nobody ever waits on another block:
+//       no spin, no dependence on co-residency, every wave reaches the end of its list (cdna_hip_programming.md §5 "Projection
+//       GEMM at M = 256" item 2 is the protocol; tickets are returned to zero by the reducer, so a completed launch leaves
+//       the counter words as it found them: zero).
+//   item boundary: the wave group that runs one barrier ahead lets the other catch up, every wave drains its accumulators
+//   (plain bf16 tiles go through a private 16-row LDS staging strip BESIDE the 128 KB of operand buffers, which are already
+//   receiving the next item), clears them and the stagger is re-established.  Extra barriers only add ordering.
+// =================================================================================================
+#define P8S_MAX_ITEMS 48
+struct P8Sched { int G, Gr, full_rounds, R, nt, pp, P; int* tickets; float* slabs; };     // P = R * pp pairs (fits 31 bits: host-checked)
+struct P8Item { int m0, n0, kb, ke, rt; };
+
+__device__ __forceinline__ void p8_tile_of(const FastArgs& g, int L, int& tm, int& tn) {
+    const int per_group = 8 * g.tiles_n;
+    const int grp = L / per_group, first_tm = grp * 8;
+    const int gsz = (g.tiles_m - first_tm) < 8 ? (g.tiles_m - first_tm) : 8;
+    const int in_g = L - grp * per_group;
+    tm = first_tm + in_g % gsz; tn = in_g / gsz;
+}
+// pair range [lo, hi) of the remainder that block b owns (empty for b >= Gr)
+__device__ __forceinline__ void p8_range(const P8Sched& sc, int b, int& lo, int& hi) {
+    if (b >= sc.Gr) { lo = hi = 0; return; }
+    lo = (int)((long long)b * sc.P / sc.Gr); hi = (int)((long long)(b + 1) * sc.P / sc.Gr);
+}
+__device__ __forceinline__ int p8_num_items(const P8Sched& sc, int lo, int hi) {
+    int n = sc.full_rounds;
+    if (hi > lo) { n += 1; if (hi > (lo / sc.pp + 1) * sc.pp) n += 1; }
+    return n;
+}
+__device__ __forceinline__ P8Item p8_item(const FastArgs& g, const P8Sched& sc, int b, int j, int lo, int hi) {
+    P8Item it; int L;
+    // whole tiles first, the shared (remainder) items last.  Measured the other way round (remainder first, so that the slab
+    // traffic runs under the other blocks' whole tiles): 15-25 % SLOWER — blocks leave the remainder at different times and the
+    // 32 blocks of an XCD then no longer walk K in lockstep, which is what lets one fetched panel slice serve 4-8 of them from L2
+    if (j < sc.full_rounds) { L = j * sc.G + (b & 7) * (sc.G >> 3) + (b >> 3); it.kb = 0; it.ke = sc.nt; it.rt = -1; }
+    else {
+        const int t1 = lo / sc.pp;
+        if (j == sc.full_rounds) {
+            const int e = hi < (t1 + 1) * sc.pp ? hi : (t1 + 1) * sc.pp;
+            it.rt = t1; it.kb = (lo - t1 * sc.pp) * 2; it.ke = (e - t1 * sc.pp) * 2;
+        } else { it.rt = t1 + 1; it.kb = 0; it.ke = (hi - (t1 + 1) * sc.pp) * 2; }
+        L = sc.full_rounds * sc.G + it.rt;
+        if (it.kb == 0 && it.ke == sc.nt) it.rt = -1;                   // the whole tile after all: no sharing
+    }
+    int tm, tn; p8_tile_of(g, L, tm, tn);
+    it.m0 = tm * 256; it.n0 = tn * 256;
+    return it;
+}
+// block that owns remainder pair x (ranges are floor(b*P/Gr) .. floor((b+1)*P/Gr))
+__device__ __forceinline__ int p8_owner(const P8Sched& sc, int x) { return (int)((((long long)x + 1) * sc.Gr - 1) / sc.P); }
+
+#define P8S_STAGE_BYTES (16 * 144)            // per-wave epilogue strip: 16 rows x (128 B + 16 B pad)
+template <typename TC>
+__global__ __launch_bounds__(512, 2)
+void gemm_nt_bf16_p8_kernel(FastArgs g, P8Sched sc) {
+    // one LDS array (a second __shared__ object next to an LDS-DMA staging array can make hipcc drain vmcnt before every
+    // ds_read): 128 KB operand buffers | 8 private epilogue strips | ticket flag | the block's item table
+    __shared__ __attribute__((aligned(16))) bf16_t smem[2 * 4 * P8_HT + (8 * P8S_STAGE_BYTES + 64 + P8S_MAX_ITEMS * 32) / 2];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int b = blockIdx.x;
+    // remainder ranges are dealt in XCD order too: the blocks of one XCD (b, b+8, ...) take CONSECUTIVE ranges, i.e. neighbouring
+    // tiles of the grouped order that share operand panels in that XCD's L2, and the sharers of a tile sit on one XCD (the
+    // reducer reads same-XCD slabs).  v = position of this block in that order; slabs and owners are indexed by v.
+    const int v = (sc.Gr & 7) == 0 ? ((b & 7) * (sc.Gr >> 3) + (b >> 3)) : b;
+    int lo, hi;
+    p8_range(sc, (b < sc.Gr) ? v : sc.Gr, lo, hi);
+    const int n_items = p8_num_items(sc, lo, hi);
+    if (n_items == 0) return;                                          // uniform for the whole block
+    char* const extra = reinterpret_cast<char*>(smem + 2 * 4 * P8_HT);
+    char* const stage = extra + wave * P8S_STAGE_BYTES;
+    int* const flag = reinterpret_cast<int*>(extra + 8 * P8S_STAGE_BYTES);
+    int* const itab = reinterpret_cast<int*>(extra + 8 * P8S_STAGE_BYTES + 64);
+    if ((int)threadIdx.x < n_items) {                                  // item table: the divisions happen once, here
+        const P8Item it = p8_item(g, sc, b, threadIdx.x, lo, hi);
+        int* e = itab + threadIdx.x * 8;
+        e[0] = it.m0; e[1] = it.n0; e[2] = it.kb; e[3] = it.ke; e[4] = it.rt;
+    }
+    __syncthreads();
+#define P8S_ITEM(dst, j_) P8Item dst; { const int* e_ = itab + (j_) * 8; dst.m0 = __builtin_amdgcn_readfirstlane(e_[0]); dst.n0 = __builtin_amdgcn_readfirstlane(e_[1]); \
+        dst.kb = __builtin_amdgcn_readfirstlane(e_[2]); dst.ke = __builtin_amdgcn_readfirstlane(e_[3]); dst.rt = __builtin_amdgcn_readfirstlane(e_[4]); }
+
+    // ---- per-lane constants of the DMA source addressing
+    int lrA[2], lrB[2], chk[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int lr = (wave * 2 + i) * 8 + (lane >> 3);               // row of the half-tile image
+        chk[i] = ((lane & 7) ^ ((lr >> 1) & 7)) * 8;
+        lrA[i] = (lr >> 6) * 128 + (lr & 63);
+        lrB[i] = (lr >> 5) * 64 + (lr & 31);
+    }
+    unsigned offA1[2], offA0[2], offB0[2], offB1[2];                   // cursor c1 owns offA1 (A-h1 of K-tile g+1), c2 the other three (g+2)
+#define P8S_OFFA(dst, m0_, h) _Pragma("unroll") for (int i = 0; i < 2; ++i) { int ra = (m0_) + lrA[i] + (h) * 64; ra = ra < g.M ? ra : g.M - 1; \
+        dst[i] = (unsigned)(ra * g.lda + chk[i]); }
+#define P8S_OFFB(dst, n0_, h) _Pragma("unroll") for (int i = 0; i < 2; ++i) { int rb = (n0_) + lrB[i] + (h) * 32; rb = rb < g.N ? rb : g.N - 1; \
+        dst[i] = (unsigned)(rb * g.ldb + chk[i]); }
+
+    f32x4 acc[4][8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int sw = ((lane & 15) >> 1) & 7, c0 = lane >> 4;
+    int aBase[2], bBase[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        aBase[ks] = (wr * 64 + (lane & 15)) * 64 + (((c0 + 4 * ks) ^ sw) << 3);
+        bBase[ks] = (wc * 32 + (lane & 15)) * 64 + (((c0 + 4 * ks) ^ sw) << 3);
+    }
+    bf16x8 fa[2][4], fb0[2][2], fb1[2][2];
+
+#define P8_RD(off) (*reinterpret_cast<const bf16x8*>(smem + (off)))
+#define P8_LDA(b_, X) _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int ii = 0; ii < 4; ++ii) \
+        fa[ks][ii] = P8_RD(((b_) * 4 + (X)) * P8_HT + aBase[ks] + ii * 16 * 64);
+#define P8_LDB(dst, b_, X) _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int jj = 0; jj < 2; ++jj) \
+        dst[ks][jj] = P8_RD(((b_) * 4 + 2 + (X)) * P8_HT + bBase[ks] + jj * 16 * 64);
+#define P8_PF(b_, slot, base, off) _Pragma("unroll") for (int i = 0; i < 2; ++i) \
+        glds16((base) + (off)[i], smem + ((b_) * 4 + (slot)) * P8_HT + (wave * 2 + i) * 8 * 64);
+#define P8_MMA(mh, fbv, nh) __builtin_amdgcn_s_setprio(1); \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int jj = 0; jj < 2; ++jj) _Pragma("unroll") for (int ii = 0; ii < 4; ++ii) \
+            acc[(nh) * 2 + jj][(mh) * 4 + ii] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fbv[ks][jj], fa[ks][ii], acc[(nh) * 2 + jj][(mh) * 4 + ii], 0, 0, 0); \
+        __builtin_amdgcn_s_setprio(0);
+#define P8_BAR __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0);
+
+    // ---- prefetch cursors over the block's stream of K-tiles: (item index, K-tile index inside the tile, end of the item)
+    int j1 = 0, k1, ke1, j2 = 0, k2, ke2;
+    {
+        P8S_ITEM(it0, 0)
+        k1 = k2 = it0.kb; ke1 = ke2 = it0.ke;
+        P8S_OFFA(offA1, it0.m0, 1) P8S_OFFA(offA0, it0.m0, 0) P8S_OFFB(offB0, it0.n0, 0) P8S_OFFB(offB1, it0.n0, 1)
+    }
+    // step a cursor to the next K-tile of the stream; past the end of the list it stays on the last K-tile (redundant re-loads
+    // into buffers nobody reads any more keep the vmcnt arithmetic constant)
+#define P8S_ADV1 { if (k1 + 1 < ke1) ++k1; else if (j1 + 1 < n_items) { ++j1; P8S_ITEM(nx, j1) k1 = nx.kb; ke1 = nx.ke; \
+                   P8S_OFFA(offA1, nx.m0, 1) } }
+#define P8S_ADV2 { if (k2 + 1 < ke2) ++k2; else if (j2 + 1 < n_items) { ++j2; P8S_ITEM(nx, j2) k2 = nx.kb; ke2 = nx.ke; \
+                   P8S_OFFA(offA0, nx.m0, 0) P8S_OFFB(offB0, nx.n0, 0) P8S_OFFB(offB1, nx.n0, 1) } }
+#define P8S_TILE(b_) { \
+        /* ph1 */ P8_LDB(fb0, b_, 0) __builtin_amdgcn_sched_barrier(0); P8_LDA(b_, 0) P8_PF((b_) ^ 1, 1, g.A + (long long)k1 * FT_BK, offA1) \
+        asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory"); P8_BAR P8_MMA(0, fb0, 0) P8_BAR \
+        P8S_ADV1 \
+        /* ph2 */ P8_LDB(fb1, b_, 1) P8_PF(b_, 2, g.B + (long long)k2 * FT_BK, offB0) P8_BAR P8_MMA(0, fb1, 1) P8_BAR \
+        /* ph3 */ P8_LDA(b_, 1) P8_PF(b_, 0, g.A + (long long)k2 * FT_BK, offA0) P8_BAR P8_MMA(1, fb1, 1) P8_BAR \
+        /* ph4 */ P8_PF(b_, 3, g.B + (long long)k2 * FT_BK, offB1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); P8_BAR P8_MMA(1, fb0, 0) P8_BAR \
+        P8S_ADV2 \
+    }
+
+    // ---- prologue: stream tile 0 complete, three half-tiles of stream tile 1 in flight (its A-h1 follows in tile 0's ph1)
+    {
+        const bf16_t* pA0 = g.A + (long long)k2 * FT_BK;
+        const bf16_t* pB0 = g.B + (long long)k2 * FT_BK;
+        P8_PF(0, 2, pB0, offB0) P8_PF(0, 0, pA0, offA0) P8_PF(0, 3, pB0, offB1) P8_PF(0, 1, pA0, offA1)
+        P8S_ADV1 P8S_ADV2                                              // both cursors on stream tile 1
+        const bf16_t* pA1 = g.A + (long long)k2 * FT_BK;
+        const bf16_t* pB1 = g.B + (long long)k2 * FT_BK;
+        P8_PF(1, 2, pB1, offB0) P8_PF(1, 0, pA1, offA0) P8_PF(1, 3, pB1, offB1)
+        P8S_ADV2                                                       // c2 on stream tile 2; c1 stays on tile 1 (its A-h1 is issued by tile 0's ph1)
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        P8_BAR
+    }
+
+    for (int jc = 0; jc < n_items; ++jc) {
+        P8S_ITEM(it, jc)
+        if (wr == 1) { P8_BAR }                                        // second wave group runs one barrier behind
+        for (int t = it.kb; t < it.ke; t += 2) {
+            P8S_TILE(0)
+            P8S_TILE(1)
+        }
+        if (wr == 0) { P8_BAR }                                        // aligned again: every wave is past its last MFMA of this item
+        const int mb = it.m0 + wr * 128, nb = it.n0 + wc * 64;
+
+        // ---- shared tile: publish the partial sums, the last arriver reduces
+        bool do_epilogue = true;
+        if (it.rt >= 0) {
+            const int t0 = it.rt * sc.pp;
+            const int b_first = p8_owner(sc, t0), b_last = p8_owner(sc, t0 + sc.pp - 1);
+            const int which = (it.rt == lo / sc.pp) ? 0 : 1;
+            f32x4* my = reinterpret_cast<f32x4*>(sc.slabs) + ((long long)(v * 2 + which) * 8 + wave) * 2048;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) my[(j * 8 + i) * 64 + lane] = acc[j][i];
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (threadIdx.x == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                const int tk = __hip_atomic_fetch_add(sc.tickets + it.rt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                *flag = tk;
+            }
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            const int tk = *const_cast<volatile int*>(flag);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                              // everybody has read the flag before it can be rewritten
+            do_epilogue = (tk == b_last - b_first);
+            if (do_epilogue) {                                         // block-uniform
+                if (threadIdx.x == 0) {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    __hip_atomic_store(sc.tickets + it.rt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // leave the counter as we found it
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                // two sharers: mine + theirs (commutative, so the arrival order cannot show).  More: sum EVERY slab in block order,
+                // my own included (read back from the workspace), so the result does not depend on who arrived last
+                const bool all = (b_last - b_first) >= 2;
+                if (all) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                }
+                for (int ob = b_first; ob <= b_last; ++ob) {                 // ob, b_first, b_last: positions in the v order
+                    if (ob == v && !all) continue;
+                    int olo, ohi;
+                    p8_range(sc, ob, olo, ohi);
+                    const int ow = (it.rt == olo / sc.pp) ? 0 : 1;
+                    const f32x4* os = reinterpret_cast<const f32x4*>(sc.slabs) + ((long long)(ob * 2 + ow) * 8 + wave) * 2048;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) acc[j][i] += os[(j * 8 + i) * 64 + lane];
+                }
+            }
+        }
+
+        if (do_epilogue) {
+            if (sizeof(TC) == 2 && !g.bias && !g.residual && !g.accumulate && g.act == 0 && g.alpha == 1.0f &&
+                nb + 64 <= g.N && (g.ldc & 7) == 0 && ((uintptr_t)g.C & 15) == 0) {          // wave-uniform
+                // plain bf16 tile: 16 rows x 64 columns at a time through the wave's private strip, out as 128-B row segments
+                bf16_t* C = reinterpret_cast<bf16_t*>(g.C);
+#pragma unroll
+                for (int ii = 0; ii < 8; ++ii) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const f32x4 v = acc[j][ii];
+                        u32x2 o;
+                        o[0] = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+                        o[1] = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+                        *reinterpret_cast<u32x2*>(stage + (lane & 15) * 144 + (j * 16 + (lane >> 4) * 4) * 2) = o;
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int itr = 0; itr < 2; ++itr) {
+                        const int r = itr * 8 + (lane >> 3), ch = lane & 7;
+                        const u32x4 v = *reinterpret_cast<const u32x4*>(stage + r * 144 + ch * 16);
+                        const int m = mb + ii * 16 + r;
+                        if (m < g.M) *reinterpret_cast<u32x4*>(C + (long long)m * g.ldc + nb + ch * 8) = v;
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // strip is read before the next pass overwrites it
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {
+                gemm_epilogue<TC, 8>(g, acc, mb, nb, lane);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // the tail's redundant DMAs drain before the block's LDS is released
+#undef P8S_TILE
+#undef P8S_ITEM
+#undef P8S_ADV2
+#undef P8S_ADV1
+#undef P8S_OFFB
+#undef P8S_OFFA
+#undef P8_BAR
+#undef P8_MMA
+#undef P8_PF
+#undef P8_LDB
+#undef P8_LDA
+#undef P8_RD
+}
+
+
 // split-K combine: C = act(alpha * sum_s slab[s] + bias) + residual (+C); 4 columns per thread (16-B slab loads)
 template <typename TC>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(FastArgs g) {
@@ -501,6 +792,7 @@ static int tile_choice(const egomi_gemm_desc* d) {
     return (d->M >= 2048 && d->N >= 8192) ? 2 : 1;
 }
 
+static bool p8_applicable(const egomi_gemm_desc* d, struct P8Sched& sc);
 extern "C" int egomi_gemm_kernel_id(const egomi_gemm_desc* d) {
     if (!d) return EGOMI_E_BADARG;
     if (d->force_generic || !fast_applicable(d)) return 0;
@@ -582,6 +874,54 @@ static TailPlan plan_tail(int M, int N, int K, long long ws_bytes) {
     return best;
 }
 
+// persistent launch: schedule in a handful of integers, everything else is derived inside the kernel.  Needs the caller's
+// workspace (4 KB of ticket words, zero on entry and left zero, then G*2 slabs of 256 KB) and an even number of K-tiles.
+static int p8_cus() {
+    static int n = 0;
+    if (!n) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v >= 8) n = v & ~7;
+        else n = 256;
+    }
+    return n;
+}
+static bool p8_applicable(const egomi_gemm_desc* d, P8Sched& sc) {
+    static int off = -1;
+    if (off < 0) { const char* e = getenv("EGOMI_GEMM_PERSIST"); off = (e && atoi(e) == 0) ? 1 : 0; }
+    if (off || !d->workspace || !d->ws_tickets_zeroed || d->split_k > 0) return false;
+    const int nt = d->K / FT_BK;
+    if (nt < 4 || (nt & 1)) return false;
+    const int tm = (d->M + 255) / 256, tn = (d->N + 255) / 256;
+    const long long T = (long long)tm * tn;
+    sc.G = p8_cus();
+    if ((long long)4096 + (long long)sc.G * 2 * 262144 > d->workspace_bytes) return false;
+    sc.full_rounds = (int)(T / sc.G); sc.R = (int)(T % sc.G); sc.nt = nt; sc.pp = nt / 2;
+    if (sc.full_rounds + 2 > P8S_MAX_ITEMS || sc.R > 1000) return false;
+    // measured at M = 5536 (tools/gemm_bench.py, A/B in one process): +1...5 % over the per-tile kernel + combine launch when the
+    // remainder is at most half a round and K >= 4096; a large remainder (N = 11008: 178 of 256) loses 12 % — its sharers walk
+    // K out of step, so the remainder phase misses in L2 — and at K = 2048 the two forms tie.  EGOMI_GEMM_PERSIST=2 forces it.
+    static int force = -1;
+    if (force < 0) { const char* e = getenv("EGOMI_GEMM_PERSIST"); force = (e && atoi(e) == 2) ? 1 : 0; }
+    if (!force && d->ws_tickets_zeroed != 2 && (nt < 64 || sc.R * 2 > sc.G)) return false;
+    sc.P = sc.R * sc.pp;
+    sc.Gr = sc.R == 0 ? 8 : (sc.G < 4 * sc.R ? sc.G : 4 * sc.R);          // <= ~4 sharers per remainder tile
+    if (sc.P > 0 && sc.Gr > sc.P) sc.Gr = sc.P;
+    if (sc.Gr >= 8) sc.Gr &= ~7;                                             // multiple of 8: remainder ranges follow the XCD order too
+    sc.tickets = (int*)d->workspace;
+    sc.slabs = (float*)((char*)d->workspace + 4096);
+    return true;
+}
+static int launch_p8(const egomi_gemm_desc* d, FastArgs& g, const P8Sched& sc, hipStream_t s) {
+    g.tiles_m = (d->M + 255) / 256; g.tiles_n = (d->N + 255) / 256;
+    g.splitk = 1; g.ws = nullptr; g.full_tm = g.tiles_m; g.full_tiles = g.tiles_m * g.tiles_n; g.tail_s = 1;
+    const long long T = (long long)g.tiles_m * g.tiles_n;
+    const int grid = T < sc.G ? (sc.Gr > 0 ? sc.Gr : 1) : sc.G;          // fewer tiles than CUs: only the sharers of the remainder have work
+    if (d->c_dtype == EGOMI_BF16) EGOMI_LAUNCH(gemm_nt_bf16_p8_kernel<bf16_t>, dim3(grid), dim3(512), 0, s, g, sc);
+    else if (d->c_dtype == EGOMI_F32) EGOMI_LAUNCH(gemm_nt_bf16_p8_kernel<float>, dim3(grid), dim3(512), 0, s, g, sc);
+    else return EGOMI_E_UNSUPPORTED;
+    return egomi_launch_status();
+}
+
 static int launch_8phase(const egomi_gemm_desc* d, FastArgs& g, hipStream_t s) {
     g.tiles_m = (d->M + 255) / 256; g.tiles_n = (d->N + 255) / 256;
     g.splitk = 1; g.ws = (float*)d->workspace;
@@ -622,13 +962,23 @@ static int launch_8phase(const egomi_gemm_desc* d, FastArgs& g, hipStream_t s) {
 }
 
 // returns 0 on success, <0 on error, 1 when the tuned kernel does not apply
-int egomi_gemm_fast_try(const egomi_gemm_desc* d, hipStream_t s) {
-    if (!fast_applicable(d)) return 1;
+int egomi_gemm_fast_try(const egomi_gemm_desc* d0, hipStream_t s) {
+    if (!fast_applicable(d0)) return 1;
+    egomi_gemm_desc dl = *d0;
+    const egomi_gemm_desc* d = &dl;
     FastArgs g;
     g.A = (const bf16_t*)d->A; g.B = (const bf16_t*)d->B; g.C = d->C; g.bias = (const bf16_t*)d->bias; g.residual = d->residual;
     g.M = d->M; g.N = d->N; g.K = d->K; g.lda = d->lda; g.ldb = d->ldb; g.ldc = d->ldc; g.ldr = d->ldr;
     g.alpha = d->alpha; g.accumulate = d->accumulate; g.act = d->act;
     const int tc = tile_choice(d);
+    if (tc == 8 && (long long)d->M * d->lda < (1ll << 31) && (long long)d->N * d->ldb < (1ll << 31)) {
+        P8Sched sc;
+        if (p8_applicable(d, sc)) return launch_p8(d, g, sc, s);
+    }
+    if (dl.ws_tickets_zeroed && dl.workspace) {                       // the ticket words belong to the persistent kernel: every other user of the
+        if (dl.workspace_bytes > 4096) { dl.workspace = (char*)dl.workspace + 4096; dl.workspace_bytes -= 4096; }     // scratch starts behind them
+        else { dl.workspace = nullptr; dl.workspace_bytes = 0; }
+    }
     if (tc == 8 && (long long)d->M * d->lda < (1ll << 31) && (long long)d->N * d->ldb < (1ll << 31)) return launch_8phase(d, g, s);
     return tc == 2 ? launch_fast<256, 128>(d, g, s) : launch_fast<128, 128>(d, g, s);
 }

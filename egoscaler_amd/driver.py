@@ -192,8 +192,8 @@ def run_validation(model, data, args, device, max_batches=None):
     model.train()
     k = max(sums[4], 1.0)
     nan = float("nan")
-    return {"ADE": sums[0] / k if sums[4] else nan, "FDE": sums[1] / k if sums[4] else nan, "ADE_as_called": sums[2] / k if sums[4] else nan,
-            "GD": sums[3] / k if sums[4] else nan, "n": int(sums[4])}, dump
+    mean = lambda i: float(sums[i] / k) if sums[4] else nan            # plain floats: the records go into checkpoints read with weights_only=True
+    return {"ADE": mean(0), "FDE": mean(1), "ADE_as_called": mean(2), "GD": mean(3), "n": int(sums[4])}, dump
 
 
 def train(args, model, train_data, val_data=None, device="cuda", log=print):

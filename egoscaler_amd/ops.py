@@ -130,7 +130,7 @@ class GemmDesc(ctypes.Structure):
                 ("batch", c_i), ("batch_inner", c_i),
                 ("sA0", c_i64), ("sA1", c_i64), ("sB0", c_i64), ("sB1", c_i64), ("sC0", c_i64), ("sC1", c_i64),
                 ("alpha", c_f), ("accumulate", c_i), ("act", c_i), ("force_generic", c_i),
-                ("workspace", c_p), ("workspace_bytes", c_i64), ("split_k", c_i)]
+                ("workspace", c_p), ("workspace_bytes", c_i64), ("split_k", c_i), ("ws_tickets_zeroed", c_i)]
 
 
 ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
@@ -160,17 +160,18 @@ PROFILER = None
 _TAIL_WS = {}
 
 
-def _tail_workspace(device, nbytes=128 << 20):
-    """One fp32 scratch buffer per device, shared by every large product (launches are stream-ordered)."""
+def _tail_workspace(device, nbytes=(4096 + 256 * 2 * 262144)):
+    """One fp32 scratch buffer per device, shared by every large product (launches are stream-ordered): 4 KB of ticket words
+    (zero here, returned to zero by every launch: include/egomi.h `ws_tickets_zeroed`) + the fp32 slabs of shared tiles."""
     ws = _TAIL_WS.get(device)
     if ws is None:
-        ws = _TAIL_WS[device] = torch.empty(nbytes // 4, dtype=torch.float32, device=device)
+        ws = _TAIL_WS[device] = torch.zeros(nbytes // 4, dtype=torch.float32, device=device)
     return ws
 
 
 def gemm_raw(A, B, C, M, N, K, lda, ldb, ldc, a_layout=0, b_layout=0, bias=None, residual=None, ldr=0,
              act=0, alpha=1.0, accumulate=False, batch=1, batch_inner=1, strides=(0, 0, 0, 0, 0, 0), force_generic=False,
-             workspace=None, split_k=0):
+             workspace=None, split_k=0, persistent=None):
     """C = act(alpha*A.B + bias) + residual (+C).  A/B/C are tensors whose data_ptr() is the first
     element of the (first) operand; all strides in elements.  See include/egomi.h."""
     if A.dtype != B.dtype:
@@ -191,7 +192,11 @@ def gemm_raw(A, B, C, M, N, K, lda, ldb, ldc, a_layout=0, b_layout=0, bias=None,
     d.sA0, d.sA1, d.sB0, d.sB1, d.sC0, d.sC1 = strides
     d.alpha, d.accumulate, d.act, d.force_generic = alpha, int(accumulate), act, int(force_generic)
     if workspace is None and M >= 1024 and batch <= 1:
-        workspace = _tail_workspace(A.device)            # fp32 slabs for the ragged last round of the 256x256 kernel
+        workspace = _tail_workspace(A.device)            # ticket words + fp32 slabs for the shared tiles of the 256x256 kernel
+        if persistent is False:                          # A/B runs, tests: the non-persistent kernel + combine launch; its slabs must
+            workspace = workspace[1024:]                 # stay clear of the ticket words the persistent launches rely on
+        else:
+            d.ws_tickets_zeroed = 2 if persistent else 1  # True: wherever the persistent form can run; None: the library's measured rule
     if workspace is not None:
         d.workspace, d.workspace_bytes, d.split_k = workspace.data_ptr(), workspace.numel() * workspace.element_size(), split_k
     for t in (A, B, C):

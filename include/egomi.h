@@ -127,9 +127,17 @@ typedef struct egomi_gemm_desc {
      * are cut into K-slices so the ragged last round fills the chip; their slabs live here too (split_k 0 = planned by
      * the library, rows*16+S = explicit).  NULL = neither. */
     void* workspace; int64_t workspace_bytes; int split_k;
+    /* 1: the first 4096 bytes of `workspace` are ticket words that were ZERO when the caller first handed the buffer over and
+     * are touched by nobody else; every completed launch leaves them zero again.  With this promise (and workspace_bytes >=
+     * 4096 + CUs * 2 * 256 KiB) large products run the PERSISTENT form of the 256x256 kernel: one block per CU walks whole
+     * tiles, the remainder of the last round is shared K-slice-wise and summed inside the launch by the last block to
+     * arrive (no second kernel, nobody waits) wherever that form measured faster (K >= 4096 and a remainder of at most half
+     * a round); 2: the same promise, and the persistent form for every shape it can run (tests).  0: non-persistent kernel +
+     * separate combine launch. */
+    int ws_tickets_zeroed;
 } egomi_gemm_desc;
 int egomi_gemm(const egomi_gemm_desc* desc, egomi_stream_t stream);
-/* which kernel egomi_gemm would run for this descriptor: 2 = 256x256 8-phase bf16 NT kernel, 1 = 128x128 / 256x128 bf16
+/* which kernel egomi_gemm would run for this descriptor: 2 = 256x256 8-phase bf16 NT kernel (either form), 1 = 128x128 / 256x128 bf16
  * NT kernel, 0 = generic */
 int egomi_gemm_kernel_id(const egomi_gemm_desc* desc);
 

@@ -59,7 +59,10 @@ def test_config5_bs256_graph_decode_properties():
     seq_g, sc_g = seq_g.clone(), torch.stack(sc_g, 0).clone()
     assert bool(torch.isfinite(sc_g).all())
     assert torch.equal(sc_g.argmax(-1).t().contiguous(), seq_g[:, Lp:]), "greedy id must be the arg-max of its score row"
-    assert torch.equal(seq_g[:4].repeat(B // 4, 1), seq_g), "rows that share a prompt must decode identically"
+    # rows r and r + 16k hold the same prompt at the same position of their prefill chunk: identical arithmetic, identical ids.
+    # (Rows at different chunk positions need not be bit-equal: the last 256-row tile rows of a prefill GEMM are K-sliced into
+    # fp32 slabs — csrc/gemm_fast.hip plan_tail — which changes the summation order for those rows only.)
+    assert torch.equal(seq_g[:16].repeat(B // 16, 1), seq_g), "rows that share a prompt and a chunk position must decode identically"
     assert torch.equal(seq_g[:, :Lp], ids)
 
     # second replay from the same prefill state: bit-equal

@@ -87,8 +87,8 @@ def test_backward_overwrites_unless_accumulating():
         call(b, z)
         g1 = {n: g.clone() for n, g in m.engine.main_grad.items()}
         call(b, z)                                                     # second step, same batch: must equal a single fresh backward
-        for n, g in m.engine.main_grad.items():
-            assert torch.equal(g, g1[n]), (dtype, n)
+        for n, g in m.engine.main_grad.items():                        # (the embedding gradient is a scatter of atomic adds: equal up to fp32 summation order)
+            assert torch.allclose(g, g1[n], rtol=1e-5, atol=1e-6 * float(g1[n].abs().max()) + 1e-12), (dtype, n)
         m.accumulate_grads = True
         call(b, z)
         for n, g in m.engine.main_grad.items():
@@ -159,7 +159,8 @@ def test_ragged_descriptions_are_masked_and_do_standard_round_trips(tmp_path):
     # targets: tokens -> values -> denorm == ground truth within one bin of the standardised scale
     Lp = b["prompts"].shape[1]
     vals, n = T.detokenize_batch(b["tokens"][:, Lp - 7:], dims.tok, 9)
-    assert n.tolist() == [5] * 4
+    assert n.tolist() == [6] * 4                                          # 5 steps + the trailing "<te>" segment, which copies the last step (utils.py:88-90)
+    assert torch.equal(vals[:, 5], vals[:, 4])
     rec = norm.denorm(vals[:, :5].cpu().numpy(), b["max_abs"].cpu().numpy())
     gt = b["trajectories"].cpu().numpy()
     binw = 2.0 / (dims.tok.num_bins - 1)

@@ -362,6 +362,41 @@ def test_gemm_8phase_kernel(ops, M, N, K):
     assert torch.equal(x1, x2)
 
 
+@pytest.mark.parametrize("M,N,K", [(5536, 4096, 4096), (5536, 12288, 4096), (2900, 4100, 2048), (4096, 4096, 2048), (1500, 8200, 4224),
+                                   (5536, 4096, 11008), (3000, 3000, 2112)])
+def test_gemm_persistent_8phase_kernel(ops, M, N, K):
+    """Persistent form of the 256x256 kernel (one block per CU walking whole tiles + an in-launch, last-arriver reduction of
+    the K-sliced remainder): one full round + remainder, several rounds, fewer tiles than CUs (pure stream-K), an exact
+    multiple of the CU count (no remainder), ragged M / N edges, long K, and an odd K-tile count (falls back).  Every
+    epilogue form; repeated launches are bit-identical (fixed summation order) and leave the ticket words zero."""
+    a, w = rnd(M, K, dtype=torch.bfloat16, seed=31), rnd(N, K, dtype=torch.bfloat16, seed=32, scale=0.05)
+    bias, res = rnd(N, dtype=torch.bfloat16, seed=33), rnd(M, N, dtype=torch.bfloat16, seed=34)
+    A, W, Bi, R = a.cuda(), w.cuda(), bias.cuda(), res.cuda()
+    ref = (A.float() @ W.float().t()).cpu()
+    out = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+    assert _kernel_id(ops, A, W, out, M, N, K) == 2
+    close(ops.mm(A, W, out=out, persistent=True), ref, 2e-2)
+    old = ops.mm(A, W, persistent=False)                                            # non-persistent kernel, same operands
+    assert float((out.float() - old.float()).abs().max()) <= 8e-3 * float(ref.abs().max())
+    close(ops.mm(A, W, bias=Bi, act=ops.ACT_GELU, residual=R, alpha=0.5, persistent=True), F.gelu(0.5 * ref + bias.float()) + res.float(), 2e-2)
+    close(ops.mm(A, W, residual=R, persistent=True), ref + res.float(), 2e-2)
+    acc = R.clone()
+    close(ops.mm(A, W, out=acc, accumulate=True, persistent=True), ref + res.float(), 2e-2)
+    f32 = torch.full((M, N), 2.0, dtype=torch.float32, device="cuda")
+    ops.mm(A, W, out=f32, accumulate=True, persistent=True)
+    close(f32, ref + 2.0, 1e-3)
+    big = torch.zeros(M, N + 64, dtype=torch.bfloat16, device="cuda")               # output into a column window (ldc > N)
+    ops.mm(A, W, out=big[:, 32:32 + N], persistent=True)
+    close(big[:, 32:32 + N], ref, 2e-2)
+    assert float(big[:, :32].abs().max()) == 0 and float(big[:, 32 + N:].abs().max()) == 0
+    x1 = ops.mm(A, W, out_dtype=torch.float32, persistent=True).clone()
+    for _ in range(5):
+        assert torch.equal(ops.mm(A, W, out_dtype=torch.float32, persistent=True), x1)              # fp32 output: any change of summation order would show
+    close(ops.mm(A, W), ref, 2e-2)                                                   # whatever the library's own rule picks
+    torch.cuda.synchronize()
+    assert int(ops._tail_workspace(A.device)[:1024].view(torch.int32).abs().max()) == 0
+
+
 def _ref_attention(qkv, B, S, H, hd, scale, causal, km):
     x = qkv.float().view(B, S, 3, H, hd)
     q, k, v = x[:, :, 0].transpose(1, 2), x[:, :, 1].transpose(1, 2), x[:, :, 2].transpose(1, 2)

@@ -139,7 +139,7 @@ def test_bf16_mode_error_bounded_by_reference_bf16_error(tiny, golden_dir, unfre
     autocast, tests/golden/tiny_model_bf16.npz).  The bound is derived from the second: the reference's own bf16 run sits
     `relerr_vs_fp32` away from its fp32 run (loss 5.3e-3, gradients 0.8-2.4 %); this path must stay within
     BF16_SLACK x that distance of the fp32 golden (+ a 3e-3 floor for tensors where the reference happened to land close)."""
-    BF16_SLACK = 2.0
+    BF16_SLACK = 1.5          # measured on MI355X: every tensor lands BELOW the reference's own bf16 distance (0.6-0.97 x)
     g, dims, toks, masks, Lp, pts = tiny
     gb = np.load(os.path.join(golden_dir, "tiny_model_bf16.npz"), allow_pickle=False)
     tag = "unfrozen" if unfreeze else "frozen"

@@ -24,9 +24,9 @@ pytestmark = pytest.mark.gpu
 
 B, TEXT, STEPS, MAXT = 8, 16, 20, 160
 LAYERS = 2
-FRO_TOL = 2.5e-2          # ||got - ref||_F / ||ref||_F
-MAX_TOL = 8e-2            # max|got - ref| / max|ref|
-LOSS_TOL = 5e-3           # relative
+FRO_TOL = 2.5e-2          # ||got - ref||_F / ||ref||_F     (measured: gradients 0.4-1.3e-2, final hidden 1.1e-2)
+MAX_TOL = 4e-2            # max|got - ref| / max|ref|        (measured: gradients 0.3-1.0e-2, final hidden 2.3e-2)
+LOSS_TOL = 5e-4           # relative                         (measured: 2.8e-5)
 
 
 def _dims():

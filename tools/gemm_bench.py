@@ -7,28 +7,32 @@ import torch
 from egoscaler_amd import ops
 
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 5536
-shapes = [(4096, 4096), (12288, 4096), (11008, 4096), (22016, 4096), (4096, 11008), (1024, 384), (4096, 2048)]
+shapes = [(4096, 4096), (12288, 4096), (11008, 4096), (22016, 4096), (4096, 11008), (4096, 12288), (4096, 22016), (4096, 2048)]
 bufs = {}
 for N, K in shapes:
     a = (torch.randn(M, K, device="cuda") * 1.0).bfloat16()
     w = (torch.randn(N, K, device="cuda") * 0.02).bfloat16()
     c = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
     bufs[(N, K)] = (a, w, c)
-res = {s: [] for s in shapes}
-for rnd in range(6):
+# A/B in one process, interleaved rounds (cdna_hip_programming.md §5.4 rule 24): persistent form vs non-persistent + combine launch
+res = {(s, p): [] for s in shapes for p in (True, False)}
+for rnd in range(7):
     for s in shapes:
-        a, w, c = bufs[s]
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        ops.mm(a, w, out=c)
-        e0.record()
-        for _ in range(5):
-            ops.mm(a, w, out=c)
-        e1.record()
-        torch.cuda.synchronize()
-        if rnd:
-            res[s].append(e0.elapsed_time(e1) / 5)
-for (N, K), t in res.items():
-    t = sorted(t)
-    med = t[len(t) // 2]
-    tiles = ((M + 127) // 128) * ((N + 127) // 128)
-    print(f"M={M} N={N:6d} K={K:6d} tiles={tiles:5d} median {med*1e3:8.1f} us  {2*M*N*K/med/1e9:8.1f} TFLOP/s  (min {2*M*N*K/t[0]/1e9:.1f})")
+        for pers in (True, False):
+            a, w, c = bufs[s]
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ops.mm(a, w, out=c, persistent=pers)
+            e0.record()
+            for _ in range(5):
+                ops.mm(a, w, out=c, persistent=pers)
+            e1.record()
+            torch.cuda.synchronize()
+            if rnd:
+                res[(s, pers)].append(e0.elapsed_time(e1) / 5)
+for (N, K) in shapes:
+    line = f"M={M} N={N:6d} K={K:6d} tiles256={((M + 255) // 256) * ((N + 255) // 256):5d}"
+    for pers in (True, False):
+        t = sorted(res[((N, K), pers)])
+        med = t[len(t) // 2]
+        line += f" | {'persistent' if pers else 'per-tile  '} median {med*1e3:7.1f} us {2*M*N*K/med/1e9:7.1f} TF (best {2*M*N*K/t[0]/1e9:.1f})"
+    print(line)
