@@ -897,12 +897,17 @@ static bool p8_applicable(const egomi_gemm_desc* d, P8Sched& sc) {
     if ((long long)4096 + (long long)sc.G * 2 * 262144 > d->workspace_bytes) return false;
     sc.full_rounds = (int)(T / sc.G); sc.R = (int)(T % sc.G); sc.nt = nt; sc.pp = nt / 2;
     if (sc.full_rounds + 2 > P8S_MAX_ITEMS || sc.R > 1000) return false;
-    // measured at M = 5536 (tools/gemm_bench.py, A/B in one process): +1...5 % over the per-tile kernel + combine launch when the
-    // remainder is at most half a round and K >= 4096; a large remainder (N = 11008: 178 of 256) loses 12 % — its sharers walk
-    // K out of step, so the remainder phase misses in L2 — and at K = 2048 the two forms tie.  EGOMI_GEMM_PERSIST=2 forces it.
+    // Selection.  Measured at M = 5536 on one box, A/B in one process:
+    //   * tools/gemm_bench.py (the same operands launch after launch, i.e. weights resident in the 256-MB Infinity Cache):
+    //     persistent +1...5 % over the per-tile kernel + combine launch when the remainder is at most half a round and
+    //     K >= 4096; -12 % with a large remainder (N = 11008: 178 of 256 tiles), a tie at K = 2048
+    //   * bench.py, the real step (every product reads DIFFERENT weights, cold from HBM): persistent 143.5 ms/step vs 137.1,
+    //     its launches averaging 441.6 us vs 417.4 — the static assignment cannot re-balance around slow HBM fetches the way
+    //     the dispatcher does when it hands out one tile at a time, and the stream-K remainder walks K out of step (L2 misses).
+    // So the library's own rule never picks it; ws_tickets_zeroed = 2 (ops.mm(persistent=True)) or EGOMI_GEMM_PERSIST=2 do.
     static int force = -1;
     if (force < 0) { const char* e = getenv("EGOMI_GEMM_PERSIST"); force = (e && atoi(e) == 2) ? 1 : 0; }
-    if (!force && d->ws_tickets_zeroed != 2 && (nt < 64 || sc.R * 2 > sc.G)) return false;
+    if (!force && d->ws_tickets_zeroed != 2) return false;
     sc.P = sc.R * sc.pp;
     sc.Gr = sc.R == 0 ? 8 : (sc.G < 4 * sc.R ? sc.G : 4 * sc.R);          // <= ~4 sharers per remainder tile
     if (sc.P > 0 && sc.Gr > sc.P) sc.Gr = sc.P;

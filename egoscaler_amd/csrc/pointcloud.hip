@@ -7,11 +7,14 @@
 
 // =================================================================================================
 // A1  un-projection.  reference: data/tools/pcm_tools.py:68-96
-// three launches: (1) per-pixel validity -> 1 bit/pixel + per-chunk counts, (2) per-sample scan of
-// chunk counts, (3) ordered write of the selected valid pixels.  Pixel data is read once in (1)
-// (7 B/pixel) and only for the selected pixels in (3).
+// two launches, no scan pass and nobody waits on another block:
+//   (1) unp_mask_kernel : every pixel read ONCE (7 B: 16-B vector loads, 16 pixels per thread) -> 16 validity bits per
+//       thread + one count per 4096-pixel chunk
+//   (2) unp_write_kernel: each chunk's block sums the sample's chunk counts itself (<= a few KB from L2: its own offset and
+//       the sample total that fixes the subsample stride), leaves at once when none of the selected ordinals falls into it,
+//       otherwise ranks its valid pixels and writes the selected ones in row-major order.
 // =================================================================================================
-#define UNP_ITEMS 8
+#define UNP_ITEMS 16
 #define UNP_THREADS 256
 #define UNP_CHUNK (UNP_ITEMS * UNP_THREADS)
 
@@ -38,39 +41,27 @@ __device__ __forceinline__ bool unp_valid(const UnpParams& p, const uint8_t* rgb
     return ok;
 }
 
-__global__ __launch_bounds__(UNP_THREADS) void unp_mask_kernel(UnpParams p, uint8_t* mask, int32_t* chunk_cnt) {
+__global__ __launch_bounds__(UNP_THREADS) void unp_mask_kernel(UnpParams p, uint16_t* mask, int32_t* chunk_cnt) {
     const int b = blockIdx.y, ch = blockIdx.x;
     const uint8_t* rgb = p.rgb + (long long)b * p.L * 3;
     const float* depth = p.depth + (long long)b * p.L;
     const long long base = (long long)ch * UNP_CHUNK + (long long)threadIdx.x * UNP_ITEMS;
     unsigned m = 0;
-    if (base + UNP_ITEMS <= p.L && p.n_boxes == 0) {
-        // fast path: 24 B of colour + 32 B of depth per thread, no box test
-        const uint8_t* c = rgb + base * 3;
-        uint8_t cb[24];
-        if ((((uintptr_t)c) & 7) == 0) {
-            const uint2* c8 = reinterpret_cast<const uint2*>(c);
-            uint2 a0 = c8[0], a1 = c8[1], a2 = c8[2];
-            uint32_t w[6] = {a0.x, a0.y, a1.x, a1.y, a2.x, a2.y};
-#pragma unroll
-            for (int k = 0; k < 24; ++k) cb[k] = (uint8_t)(w[k >> 2] >> (8 * (k & 3)));
-        } else {
-#pragma unroll
-            for (int k = 0; k < 24; ++k) cb[k] = c[k];
-        }
-        float z[UNP_ITEMS];
-        if ((((uintptr_t)(depth + base)) & 15) == 0) {
-            f32x4 z0 = *reinterpret_cast<const f32x4*>(depth + base);
-            f32x4 z1 = *reinterpret_cast<const f32x4*>(depth + base + 4);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) { z[k] = z0[k]; z[4 + k] = z1[k]; }
-        } else {
-#pragma unroll
-            for (int k = 0; k < UNP_ITEMS; ++k) z[k] = depth[base + k];
-        }
+    const uint8_t* c = rgb + base * 3;
+    if (base + UNP_ITEMS <= p.L && p.n_boxes == 0 && ((((uintptr_t)c) | ((uintptr_t)(depth + base))) & 15) == 0) {
+        // fast path: 48 B of colour + 64 B of depth per thread as 16-B vectors, no box test
+        const u32x4* c16 = reinterpret_cast<const u32x4*>(c);
+        const u32x4 a0 = c16[0], a1 = c16[1], a2 = c16[2];
+        const uint32_t w[12] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3], a2[0], a2[1], a2[2], a2[3]};
+        const f32x4* z4 = reinterpret_cast<const f32x4*>(depth + base);
+        const f32x4 z0 = z4[0], z1 = z4[1], z2 = z4[2], z3 = z4[3];
+        const float z[UNP_ITEMS] = {z0[0], z0[1], z0[2], z0[3], z1[0], z1[1], z1[2], z1[3], z2[0], z2[1], z2[2], z2[3], z3[0], z3[1], z3[2], z3[3]};
 #pragma unroll
         for (int k = 0; k < UNP_ITEMS; ++k) {
-            bool ok = (cb[3 * k] != 0) & (cb[3 * k + 1] != 0) & (cb[3 * k + 2] != 0);
+            const int o = 3 * k;
+            const uint32_t c0 = (w[o >> 2] >> (8 * (o & 3))) & 0xFF, c1 = (w[(o + 1) >> 2] >> (8 * ((o + 1) & 3))) & 0xFF,
+                           c2 = (w[(o + 2) >> 2] >> (8 * ((o + 2) & 3))) & 0xFF;
+            bool ok = (c0 != 0) & (c1 != 0) & (c2 != 0);
             if (p.use_thres) ok = ok && (z[k] < p.d_thres);
             m |= (ok ? 1u : 0u) << k;
         }
@@ -81,9 +72,7 @@ __global__ __launch_bounds__(UNP_THREADS) void unp_mask_kernel(UnpParams p, uint
         }
     }
     const long long mi = (long long)b * p.nchunks * UNP_THREADS + (long long)ch * UNP_THREADS + threadIdx.x;
-    mask[mi] = (uint8_t)m;
-    __shared__ float red[16];
-    // integer block sum via wave popcount adds
+    mask[mi] = (uint16_t)m;
     int cnt = __popc(m);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
@@ -92,53 +81,41 @@ __global__ __launch_bounds__(UNP_THREADS) void unp_mask_kernel(UnpParams p, uint
     __syncthreads();
     if (threadIdx.x == 0) {
         int t = 0;
-        for (int w = 0; w < UNP_THREADS / 64; ++w) t += wsum[w];
+        for (int w2 = 0; w2 < UNP_THREADS / 64; ++w2) t += wsum[w2];
         chunk_cnt[b * p.nchunks + ch] = t;
     }
-    (void)red;
 }
 
-// one block per sample: exclusive scan of chunk counts (in place -> offsets), total -> out_count
-__global__ __launch_bounds__(1024) void unp_scan_kernel(int32_t* chunk_cnt, int nchunks, int n_out, int32_t* out_count) {
-    const int b = blockIdx.x;
-    int32_t* c = chunk_cnt + (long long)b * nchunks;
-    __shared__ int wtot[16];
-    __shared__ int carry_s;
-    if (threadIdx.x == 0) carry_s = 0;
-    __syncthreads();
-    for (int base = 0; base < nchunks; base += 1024) {
-        const int i = base + threadIdx.x;
-        const int v = (i < nchunks) ? c[i] : 0;
-        int x = v;   // inclusive wave scan
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            int y = __shfl_up(x, o, 64);
-            if ((threadIdx.x & 63) >= o) x += y;
-        }
-        if ((threadIdx.x & 63) == 63) wtot[threadIdx.x >> 6] = x;
-        __syncthreads();
-        int woff = 0;
-        for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) woff += wtot[w];
-        const int carry = carry_s;
-        if (i < nchunks) c[i] = carry + woff + x - v;
-        __syncthreads();
-        if (threadIdx.x == 1023) carry_s = carry + woff + x;
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        const int total = carry_s;
-        out_count[b] = (n_out > 0 && total < n_out) ? -total : total;
-    }
-}
-
-__global__ __launch_bounds__(UNP_THREADS) void unp_write_kernel(UnpParams p, const uint8_t* mask, const int32_t* chunk_off,
-                                                                const int32_t* out_count, int n_out, long long cap,
+__global__ __launch_bounds__(UNP_THREADS) void unp_write_kernel(UnpParams p, const uint16_t* mask, const int32_t* chunk_cnt,
+                                                                int32_t* out_count, int n_out, long long cap,
                                                                 double* out_points, float* out_colors) {
     const int b = blockIdx.y, ch = blockIdx.x;
-    const int total = out_count[b];
-    if (total <= 0) return;                       // nothing valid, or too few for the subsample
+    // ---- this chunk's offset and the sample total, from the chunk counts (the scan pass of the 3-launch form is gone)
+    const int32_t* cc = chunk_cnt + (long long)b * p.nchunks;
+    int pre = 0, tot = 0;
+    for (int i = threadIdx.x; i < p.nchunks; i += UNP_THREADS) {
+        const int v = cc[i];
+        tot += v;
+        pre += i < ch ? v : 0;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { pre += __shfl_xor(pre, o, 64); tot += __shfl_xor(tot, o, 64); }
+    __shared__ int red[2][UNP_THREADS / 64];
+    __shared__ int wtot[UNP_THREADS / 64];
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = pre; red[1][threadIdx.x >> 6] = tot; }
+    __syncthreads();
+    int off = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < UNP_THREADS / 64; ++w) { off += red[0][w]; total += red[1][w]; }
+    if (ch == 0 && threadIdx.x == 0) out_count[b] = (n_out > 0 && total < n_out) ? -total : total;
+    if (total <= 0 || (n_out > 0 && total < n_out)) return;           // nothing valid, or too few for the subsample
     const int stride = (n_out > 0) ? (total / n_out) : 1;
-    const int off = chunk_off[b * p.nchunks + ch];
+    const int mine = cc[ch];
+    if (mine == 0) return;
+    if (n_out > 0) {                                                   // does any selected ordinal j*stride, j < n_out, fall into [off, off+mine) ?
+        const long long j0 = ((long long)off + stride - 1) / stride;
+        if (j0 >= n_out || j0 * stride >= (long long)off + mine) return;
+    }
     const long long mi = (long long)b * p.nchunks * UNP_THREADS + (long long)ch * UNP_THREADS + threadIdx.x;
     const unsigned m = mask[mi];
     const int cnt = __popc(m);
@@ -148,7 +125,6 @@ __global__ __launch_bounds__(UNP_THREADS) void unp_write_kernel(UnpParams p, con
         int y = __shfl_up(x, o, 64);
         if ((threadIdx.x & 63) >= o) x += y;
     }
-    __shared__ int wtot[UNP_THREADS / 64];
     if ((threadIdx.x & 63) == 63) wtot[threadIdx.x >> 6] = x;
     __syncthreads();
     int woff = 0;
@@ -195,7 +171,7 @@ extern "C" size_t egomi_unproject_workspace_bytes(int B, int T, int H, int W) {
     if (B <= 0 || T <= 0 || H <= 0 || W <= 0) return 0;
     const long long L = (long long)T * H * W;
     const long long nch = unp_nchunks(L);
-    size_t mask_bytes = (size_t)B * nch * UNP_THREADS;
+    size_t mask_bytes = (size_t)B * nch * UNP_THREADS * sizeof(uint16_t);
     mask_bytes = (mask_bytes + 255) & ~(size_t)255;
     return mask_bytes + (size_t)B * nch * sizeof(int32_t);
 }
@@ -215,13 +191,12 @@ extern "C" int egomi_unproject_gather(const uint8_t* rgb, const float* depth, co
     p.T = T; p.H = H; p.W = W; p.L = L; p.pp = pp; p.fx = fx; p.fy = fy;
     p.use_thres = !(d_thres != d_thres); p.d_thres = d_thres;
     p.nchunks = unp_nchunks(L);
-    size_t mask_bytes = ((size_t)B * p.nchunks * UNP_THREADS + 255) & ~(size_t)255;
-    uint8_t* mask = (uint8_t*)workspace;
+    size_t mask_bytes = ((size_t)B * p.nchunks * UNP_THREADS * sizeof(uint16_t) + 255) & ~(size_t)255;
+    uint16_t* mask = (uint16_t*)workspace;
     int32_t* cnt = (int32_t*)((char*)workspace + mask_bytes);
     hipStream_t s = (hipStream_t)stream;
     dim3 grid(p.nchunks, B);
     EGOMI_LAUNCH(unp_mask_kernel, grid, dim3(UNP_THREADS), 0, s, p, mask, cnt);
-    EGOMI_LAUNCH(unp_scan_kernel, dim3(B), dim3(1024), 0, s, cnt, p.nchunks, n_out, out_count);
     const long long cap = n_out > 0 ? n_out : L;
     EGOMI_LAUNCH(unp_write_kernel, grid, dim3(UNP_THREADS), 0, s, p, mask, cnt, out_count, n_out, cap, out_points, out_colors);
     return egomi_launch_status();

@@ -65,7 +65,8 @@ class GradSync:
         self.wire_dtype, self.wire_min_bytes, self.bucket_bytes = wire_dtype, wire_min_bytes, bucket_bytes
         self.open, self.open_bytes = [], 0         # (name, buf) of the bucket being packed
         self.pending = []                          # works of async host collectives
-        self._scratch = {}                         # persistent wire / packing buffers by (tag, numel, dtype)
+        self._scratch = {}                         # persistent wire / packing buffers by (role, numel, dtype): buckets are processed in stream
+                                                   # order on ONE side stream, so buckets of equal size share their scratch
         self.stats = {"buckets": 0, "collective_calls": 0, "wire_bytes": 0}
         self._bucket_id = 0
         self._a2a_ok = True
@@ -109,7 +110,6 @@ class GradSync:
 
     def _reduce(self, flat, parts):
         """flat: a contiguous 1-D fp32 buffer reduced in place, or parts: tensors packed into one bucket and unpacked after."""
-        bid = self._bucket_id
         self._bucket_id += 1
         ref = flat if flat is not None else parts[0]
         dev, cuda = ref.device, ref.is_cuda
@@ -125,12 +125,12 @@ class GradSync:
         with ctx:
             if use_wire:
                 c = -(-n // (W * 8)) * 8                       # per-rank chunk, 16-B aligned in bf16
-                wire = self._buf(("wire", bid), W * c, self.wire_dtype, dev)
+                wire = self._buf("wire", W * c, self.wire_dtype, dev)
                 if W * c > n:
                     wire[n:].zero_()
                 self._pack(flat, parts, wire)
-                recv = self._buf(("recv", bid), W * c, self.wire_dtype, dev)
-                red = self._buf(("red", bid), c, self.wire_dtype, dev)
+                recv = self._buf("recv", W * c, self.wire_dtype, dev)
+                red = self._buf("red", c, self.wire_dtype, dev)
                 self._all_to_all(recv, wire, W, c)
                 _rank_sum(recv.view(W, c), red)
                 dist.all_gather_into_tensor(wire, red, group=self.group)
@@ -141,7 +141,7 @@ class GradSync:
                 if flat is not None:
                     dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
                 else:
-                    pk = self._buf(("pack", bid), n, ref.dtype, dev)
+                    pk = self._buf("pack", n, ref.dtype, dev)
                     self._pack(None, parts, pk)
                     dist.all_reduce(pk, op=dist.ReduceOp.SUM, group=self.group)
                     self._unpack(pk, None, parts)

@@ -131,9 +131,9 @@ typedef struct egomi_gemm_desc {
      * are touched by nobody else; every completed launch leaves them zero again.  With this promise (and workspace_bytes >=
      * 4096 + CUs * 2 * 256 KiB) large products run the PERSISTENT form of the 256x256 kernel: one block per CU walks whole
      * tiles, the remainder of the last round is shared K-slice-wise and summed inside the launch by the last block to
-     * arrive (no second kernel, nobody waits) wherever that form measured faster (K >= 4096 and a remainder of at most half
-     * a round); 2: the same promise, and the persistent form for every shape it can run (tests).  0: non-persistent kernel +
-     * separate combine launch. */
+     * arrive (no second kernel, nobody waits).  1: the promise is made, the library decides (today it keeps the per-tile
+     * kernel: with weights cold from HBM the persistent form measured 5 % slower in the training step, csrc/gemm_fast.hip);
+     * 2: the promise is made and the persistent form is taken for every shape it can run.  0: no promise. */
     int ws_tickets_zeroed;
 } egomi_gemm_desc;
 int egomi_gemm(const egomi_gemm_desc* desc, egomi_stream_t stream);
