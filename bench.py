@@ -50,6 +50,31 @@ def flops_per_sample(dims, S, S_traj, frozen_llm=True):
     return {"fwd": fwd_front + fwd_llm, "fwd_bwd": fwd_front + fwd_llm + bwd}
 
 
+def usable_cores():
+    """Host threads this process may actually run on: min(os.cpu_count(), scheduler affinity, cgroup CPU quota); when no quota is
+    visible the 1-GPU share of the box (16 CPUs per GPU) caps it.  Measured why: the GPU box reports 256 logical CPUs but
+    gives a 1-GPU job a 16-CPU share — 256 oracle threads ran 45x SLOWER than 16 (58.5 s vs 1.3 s for the 1-layer slice)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = max(1, int(float(q) / float(per)))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = max(1, q // per)
+        except Exception:
+            pass
+    return min(n, quota) if quota else min(n, 16 * max(1, torch.cuda.device_count()))
+
+
 def cpu_baseline(dims, Lp, threads):
     """Oracle (CPU restatement of the reference) on a bounded sample: ONE clip, full PointBERT + projector +
     splice + lm_head/CE, with a 1-layer and a 4-layer slice of the LLaMA-7B-width stack, fp32, forward+backward (frozen-LLM
@@ -89,7 +114,7 @@ def cpu_baseline(dims, Lp, threads):
     per_layer = max((times[4] - times[1]) / 3.0, 1e-6)
     total = t_front + times[1] + (dims.lm.num_hidden_layers - 1) * per_layer
     return {"value": 1.0 / total, "unit": "clips/s", "cores": threads, "kind": "port",
-            "sample": (f"1 clip (8x224x224) fwd+bwd fp32, frozen-LLM mode, oracle on all {threads} host threads (os.cpu_count()): "
+            "sample": (f"1 clip (8x224x224) fwd+bwd fp32, frozen-LLM mode, oracle on {threads} host threads (every core this job may use: bench.usable_cores(); the box reports {os.cpu_count()} logical CPUs): "
                        f"un-projection+pc_norm {t_front:.2f}s, PointBERT+projector+1 LLaMA-7B-width layer+lm_head/CE {times[1]:.2f}s, 4-layer slice "
                        f"{times[4]:.2f}s -> {per_layer:.2f}s per extra layer; 32-layer time extrapolated linearly = {total:.1f}s")}
 
@@ -164,9 +189,19 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gemm-events", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo only to rehearse the N>1 code path on one GPU")
+    ap.add_argument("--workload", default="train", choices=["train", "decode"],
+                    help="train: BASELINE.json configs[1], the headline (default).  decode: configs[4], bs=256 greedy decode of 32 steps in one hipGraph "
+                         "(tokens/s + HBM roofline; 1 GPU)")
     ap.add_argument("--dry-launch", action="store_true", help="launcher self-test: ranks rendezvous (gloo, host tensors), check the world size and exit without touching the GPU")
     a = ap.parse_args()
 
+    if a.workload == "decode":
+        if a.gpus != 1:
+            raise SystemExit("--workload decode is a single-GPU configuration (BASELINE.json configs[4])")
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import bench_decode
+        print(json.dumps(bench_decode.run(batch=256, steps=32)), flush=True)
+        return
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(launch_ranks(a))                    # parent: spawns the ranks, never touches the GPU itself
     rank = int(os.environ.get("RANK", 0))
@@ -341,7 +376,7 @@ def main():
         out["clocks"] = smi.summary() if smi is not None else None
         if world == 1 and not a.no_cpu_baseline:
             try:
-                out["cpu_baseline"] = cpu_baseline(dims_7b(), Lp, os.cpu_count() or 1)
+                out["cpu_baseline"] = cpu_baseline(dims_7b(), Lp, usable_cores())
             except Exception as e:      # the oracle is a reported baseline; never fail the bench on it
                 out["cpu_baseline"] = {"value": None, "unit": "clips/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
         print(json.dumps(out), flush=True)

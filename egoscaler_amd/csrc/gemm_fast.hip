@@ -33,6 +33,8 @@ struct FastArgs {
     int tiles_m, tiles_n;
     int splitk; float* ws;           // splitk > 1: block (tile, blockIdx.y) multiplies its K slice and stores a raw fp32 slab
     int full_tm, full_tiles, tail_s; // 8-phase kernel: M-tile rows >= full_tm are cut into tail_s K-slices (fp32 slabs of those rows only)
+    int* tickets;                    // non-null: the K-slices of a tail tile are summed INSIDE the launch by the slice block that arrives last
+                                     // (one ticket word per tail tile, zero on entry, returned to zero); ws then holds register-major slabs
 };
 
 typedef __attribute__((address_space(3))) void lds_void;
@@ -402,6 +404,57 @@ void gemm_nt_bf16_8phase_kernel(FastArgs g) {
     __builtin_amdgcn_s_barrier();                                 // ... for every wave (unconditional: the epilogue below re-uses the stages per wave)
     const int row0 = g.full_tm * 256;
     const int mb = m0 + wr * 128, nb = n0 + wc * 64;
+    if (ksl > 1 && g.tickets) {
+        // ---- K-sliced tail tile, combined in the launch (the protocol of the persistent kernel below; cdna_hip_programming.md §5
+        // "Projection GEMM at M = 256" item 2): every slice block drops its partial tile as a register-major fp32 slab (1-KiB wave
+        // stores), publishes it (agent-scope release) and draws a ticket; the block that draws the LAST ticket acquires, sums the
+        // slabs in slice order and runs the epilogue.  Nobody waits for anybody.
+        const int tile = (blockIdx.x - g.full_tiles) / ksl;
+        f32x4* slab = reinterpret_cast<f32x4*>(g.ws) + (long long)tile * ksl * 16384;
+        f32x4* my = slab + ((long long)kz * 8 + wave) * 2048;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) my[(j * 8 + i) * 64 + lane] = acc[j][i];
+        int* flag = reinterpret_cast<int*>(smem);                       // the operand stages are idle: every DMA has drained (above)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (threadIdx.x == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            *flag = __hip_atomic_fetch_add(g.tickets + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const int tk = *const_cast<volatile int*>(flag);
+        if (tk != ksl - 1) return;                                      // block-uniform: somebody else finishes this tile
+        if (threadIdx.x == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            __hip_atomic_store(g.tickets + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // leave the word as we found it
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        // two slices: mine + the other (commutative).  More: every slab in slice order, mine read back, so that the sum does not
+        // depend on the arrival order
+        const bool all = ksl > 2;
+        if (all) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        for (int z = 0; z < ksl; ++z) {
+            if (z == kz && !all) continue;
+            const f32x4* os = slab + ((long long)z * 8 + wave) * 2048;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) acc[j][i] += os[(j * 8 + i) * 64 + lane];
+        }
+        gemm_epilogue<TC, 8>(g, acc, mb, nb, lane);
+        return;
+    }
     if (sizeof(TC) == 2 && ksl == 1 && !g.bias && !g.residual && !g.accumulate && g.act == 0 && g.alpha == 1.0f &&
         nb + 64 <= g.N && (g.ldc & 7) == 0 && ((uintptr_t)g.C & 15) == 0) {              // wave-uniform
         // plain bf16 store: the direct form writes 8-B pieces of 16 different rows per instruction (16 line transactions
@@ -927,7 +980,7 @@ static int launch_p8(const egomi_gemm_desc* d, FastArgs& g, const P8Sched& sc, h
     return egomi_launch_status();
 }
 
-static int launch_8phase(const egomi_gemm_desc* d, FastArgs& g, hipStream_t s) {
+static int launch_8phase(const egomi_gemm_desc* d, FastArgs& g, hipStream_t s, int* tickets = nullptr) {
     g.tiles_m = (d->M + 255) / 256; g.tiles_n = (d->N + 255) / 256;
     g.splitk = 1; g.ws = (float*)d->workspace;
     static int no_tail = -1;
@@ -947,11 +1000,15 @@ static int launch_8phase(const egomi_gemm_desc* d, FastArgs& g, hipStream_t s) {
         if (tp.s < 2 || rows_rel * d->N * 4 * tp.s > d->workspace_bytes) tp = {0, 1};
     }
     g.full_tm = g.tiles_m - tp.rows; g.tail_s = tp.s; g.full_tiles = g.full_tm * g.tiles_n;
+    // in-launch combine: needs the caller's ticket words (4 KB ahead of the slabs, include/egomi.h `ws_tickets_zeroed`) and room for
+    // whole 256x256 slabs of every tail tile and slice
+    g.tickets = nullptr;
+    if (tp.rows && tickets && tp.rows * g.tiles_n <= 1024 && (long long)tp.rows * g.tiles_n * tp.s * 262144 <= d->workspace_bytes) g.tickets = tickets;
     const int nwg = g.full_tiles + tp.rows * g.tiles_n * tp.s;
     if (d->c_dtype == EGOMI_BF16) EGOMI_LAUNCH(gemm_nt_bf16_8phase_kernel<bf16_t>, dim3(nwg, 1), dim3(512), 0, s, g);
     else if (d->c_dtype == EGOMI_F32) EGOMI_LAUNCH(gemm_nt_bf16_8phase_kernel<float>, dim3(nwg, 1), dim3(512), 0, s, g);
     else return EGOMI_E_UNSUPPORTED;
-    if (tp.rows) {
+    if (tp.rows && !g.tickets) {
         FastArgs r = g;
         const long long row0 = (long long)g.full_tm * 256;
         const int esz = d->c_dtype == EGOMI_BF16 ? 2 : 4;
@@ -974,16 +1031,24 @@ int egomi_gemm_fast_try(const egomi_gemm_desc* d0, hipStream_t s) {
     FastArgs g;
     g.A = (const bf16_t*)d->A; g.B = (const bf16_t*)d->B; g.C = d->C; g.bias = (const bf16_t*)d->bias; g.residual = d->residual;
     g.M = d->M; g.N = d->N; g.K = d->K; g.lda = d->lda; g.ldb = d->ldb; g.ldc = d->ldc; g.ldr = d->ldr;
-    g.alpha = d->alpha; g.accumulate = d->accumulate; g.act = d->act;
+    g.alpha = d->alpha; g.accumulate = d->accumulate; g.act = d->act; g.tickets = nullptr;
     const int tc = tile_choice(d);
     if (tc == 8 && (long long)d->M * d->lda < (1ll << 31) && (long long)d->N * d->ldb < (1ll << 31)) {
         P8Sched sc;
         if (p8_applicable(d, sc)) return launch_p8(d, g, sc, s);
     }
-    if (dl.ws_tickets_zeroed && dl.workspace) {                       // the ticket words belong to the persistent kernel: every other user of the
-        if (dl.workspace_bytes > 4096) { dl.workspace = (char*)dl.workspace + 4096; dl.workspace_bytes -= 4096; }     // scratch starts behind them
+    int* tickets = nullptr;
+    if (dl.ws_tickets_zeroed && dl.workspace) {                       // the ticket words are used by the in-launch combines only: every other
+        if (dl.workspace_bytes > 4096) { tickets = (int*)dl.workspace; dl.workspace = (char*)dl.workspace + 4096; dl.workspace_bytes -= 4096; }   // scratch starts behind them
         else { dl.workspace = nullptr; dl.workspace_bytes = 0; }
     }
-    if (tc == 8 && (long long)d->M * d->lda < (1ll << 31) && (long long)d->N * d->ldb < (1ll << 31)) return launch_8phase(d, g, s);
+    // In-launch combine of the K-sliced tail tiles (last-arriver tickets) is built and tested but NOT the default: measured in
+    // the training step on one box, A/B in alternation, 139.1 ms/step vs 136.6 with the separate combine launch (kernel + combine
+    // 427 us vs 418 us per product).  The last arriver sums S x 256 KB of slabs alone, on the critical path at the very end of
+    // the launch, where the separate splitk_reduce_kernel spreads the same bytes over every CU.  EGOMI_GEMM_FOLD=1 selects it.
+    static int fold = -1;
+    if (fold < 0) { const char* e = getenv("EGOMI_GEMM_FOLD"); fold = e ? atoi(e) : 0; }
+    if (!fold && dl.ws_tickets_zeroed != 2) tickets = nullptr;
+    if (tc == 8 && (long long)d->M * d->lda < (1ll << 31) && (long long)d->N * d->ldb < (1ll << 31)) return launch_8phase(d, g, s, tickets);
     return tc == 2 ? launch_fast<256, 128>(d, g, s) : launch_fast<128, 128>(d, g, s);
 }

@@ -10,9 +10,9 @@
 // two launches, no scan pass and nobody waits on another block:
 //   (1) unp_mask_kernel : every pixel read ONCE (7 B: 16-B vector loads, 16 pixels per thread) -> 16 validity bits per
 //       thread + one count per 4096-pixel chunk
-//   (2) unp_write_kernel: each chunk's block sums the sample's chunk counts itself (<= a few KB from L2: its own offset and
-//       the sample total that fixes the subsample stride), leaves at once when none of the selected ordinals falls into it,
-//       otherwise ranks its valid pixels and writes the selected ones in row-major order.
+//   (2) dense form: unp_write_dense_kernel, one block per chunk: sums the sample's chunk counts itself (its own offset; a few
+//       KB from L2), then lanes walk consecutive pixels so that ranks, hence output rows, are consecutive per wave;
+//       subsample form (first-N-valid strided subsample): unp_pick_kernel, one thread per output row.
 // =================================================================================================
 #define UNP_ITEMS 16
 #define UNP_THREADS 256
@@ -41,7 +41,7 @@ __device__ __forceinline__ bool unp_valid(const UnpParams& p, const uint8_t* rgb
     return ok;
 }
 
-__global__ __launch_bounds__(UNP_THREADS) void unp_mask_kernel(UnpParams p, uint16_t* mask, int32_t* chunk_cnt) {
+__global__ __launch_bounds__(UNP_THREADS) void unp_mask_kernel(UnpParams p, uint16_t* mask, uint16_t* rank, int32_t* chunk_cnt) {
     const int b = blockIdx.y, ch = blockIdx.x;
     const uint8_t* rgb = p.rgb + (long long)b * p.L * 3;
     const float* depth = p.depth + (long long)b * p.L;
@@ -73,24 +73,46 @@ __global__ __launch_bounds__(UNP_THREADS) void unp_mask_kernel(UnpParams p, uint
     }
     const long long mi = (long long)b * p.nchunks * UNP_THREADS + (long long)ch * UNP_THREADS + threadIdx.x;
     mask[mi] = (uint16_t)m;
-    int cnt = __popc(m);
+    // exclusive rank of this thread's first valid pixel inside the chunk (the subsample pass binary-searches these)
+    const int cnt = __popc(m);
+    int x = cnt;
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
-    __shared__ int wsum[UNP_THREADS / 64];
-    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = cnt;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        int t = 0;
-        for (int w2 = 0; w2 < UNP_THREADS / 64; ++w2) t += wsum[w2];
-        chunk_cnt[b * p.nchunks + ch] = t;
+    for (int o = 1; o < 64; o <<= 1) {
+        int y = __shfl_up(x, o, 64);
+        if ((threadIdx.x & 63) >= o) x += y;
     }
+    __shared__ int wsum[UNP_THREADS / 64];
+    if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = x;
+    __syncthreads();
+    int woff = 0;
+    for (int w2 = 0; w2 < (int)(threadIdx.x >> 6); ++w2) woff += wsum[w2];
+    rank[mi] = (uint16_t)(woff + x - cnt);                              // <= 4096 - 16
+    if (threadIdx.x == UNP_THREADS - 1) chunk_cnt[b * p.nchunks + ch] = woff + x;
 }
 
-__global__ __launch_bounds__(UNP_THREADS) void unp_write_kernel(UnpParams p, const uint16_t* mask, const int32_t* chunk_cnt,
-                                                                int32_t* out_count, int n_out, long long cap,
-                                                                double* out_points, float* out_colors) {
+// un-projection of one pixel (pcm_tools.py:74-78): fp64 point, fp32 colour
+__device__ __forceinline__ void unp_emit(const UnpParams& p, const uint8_t* rgb, const float* depth, long long i, double* op, float* oc) {
+    const int hw = p.H * p.W;
+    const int r = (int)(i % hw);
+    const int v = r / p.W, u = r % p.W;
+    const double z = (double)depth[i];
+    const double xn = ((double)u - p.pp) / p.fx;              // pcm_tools.py:74
+    const double yn = ((double)v - p.pp) / p.fy;              // :75
+    op[0] = xn * z;                                           // :77
+    op[1] = yn * z;
+    op[2] = z;
+    const uint8_t* c = rgb + i * 3;
+    oc[0] = (float)c[0] / 255.0f;                             // :78 (float32 image / 255.0)
+    oc[1] = (float)c[1] / 255.0f;
+    oc[2] = (float)c[2] / 255.0f;
+}
+
+// (2a) dense form (n_out == 0): every valid pixel, in row-major order.  One block per chunk; lanes walk CONSECUTIVE pixels, so
+// the ranks a wave hands out are consecutive rows of the output and its stores land side by side (the 16-pixels-per-thread
+// mapping of the mask pass would scatter 24-B pieces: 0.65 TB/s measured).
+__global__ __launch_bounds__(UNP_THREADS) void unp_write_dense_kernel(UnpParams p, const uint16_t* mask, const int32_t* chunk_cnt,
+                                                                      int32_t* out_count, long long cap, double* out_points, float* out_colors) {
     const int b = blockIdx.y, ch = blockIdx.x;
-    // ---- this chunk's offset and the sample total, from the chunk counts (the scan pass of the 3-launch form is gone)
     const int32_t* cc = chunk_cnt + (long long)b * p.nchunks;
     int pre = 0, tot = 0;
     for (int i = threadIdx.x; i < p.nchunks; i += UNP_THREADS) {
@@ -101,68 +123,104 @@ __global__ __launch_bounds__(UNP_THREADS) void unp_write_kernel(UnpParams p, con
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { pre += __shfl_xor(pre, o, 64); tot += __shfl_xor(tot, o, 64); }
     __shared__ int red[2][UNP_THREADS / 64];
-    __shared__ int wtot[UNP_THREADS / 64];
-    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = pre; red[1][threadIdx.x >> 6] = tot; }
+    __shared__ int wcnt[UNP_THREADS / 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { red[0][wave] = pre; red[1][wave] = tot; }
+    // each wave owns 1024 consecutive pixels = 64 mask words: lane l holds word l of its wave
+    const uint16_t* mw = mask + (long long)b * p.nchunks * UNP_THREADS + (long long)ch * UNP_THREADS + wave * 64;
+    const unsigned myword = mw[lane];
+    int wc = __popc(myword);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) wc += __shfl_xor(wc, o, 64);
+    if (lane == 0) wcnt[wave] = wc;
     __syncthreads();
     int off = 0, total = 0;
 #pragma unroll
     for (int w = 0; w < UNP_THREADS / 64; ++w) { off += red[0][w]; total += red[1][w]; }
-    if (ch == 0 && threadIdx.x == 0) out_count[b] = (n_out > 0 && total < n_out) ? -total : total;
-    if (total <= 0 || (n_out > 0 && total < n_out)) return;           // nothing valid, or too few for the subsample
-    const int stride = (n_out > 0) ? (total / n_out) : 1;
-    const int mine = cc[ch];
-    if (mine == 0) return;
-    if (n_out > 0) {                                                   // does any selected ordinal j*stride, j < n_out, fall into [off, off+mine) ?
-        const long long j0 = ((long long)off + stride - 1) / stride;
-        if (j0 >= n_out || j0 * stride >= (long long)off + mine) return;
-    }
-    const long long mi = (long long)b * p.nchunks * UNP_THREADS + (long long)ch * UNP_THREADS + threadIdx.x;
-    const unsigned m = mask[mi];
-    const int cnt = __popc(m);
-    int x = cnt;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        int y = __shfl_up(x, o, 64);
-        if ((threadIdx.x & 63) >= o) x += y;
-    }
-    if ((threadIdx.x & 63) == 63) wtot[threadIdx.x >> 6] = x;
-    __syncthreads();
-    int woff = 0;
-    for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) woff += wtot[w];
-    int ord = off + woff + x - cnt;               // ordinal of this thread's first valid pixel
-    if (cnt == 0) return;
+    if (ch == 0 && threadIdx.x == 0) out_count[b] = total;
+    if (cc[ch] == 0) return;
+    for (int w = 0; w < wave; ++w) off += wcnt[w];
     const uint8_t* rgb = p.rgb + (long long)b * p.L * 3;
     const float* depth = p.depth + (long long)b * p.L;
-    const long long base = (long long)ch * UNP_CHUNK + (long long)threadIdx.x * UNP_ITEMS;
-    const int hw = p.H * p.W;
-    for (int k = 0; k < UNP_ITEMS; ++k) {
-        if (!((m >> k) & 1u)) continue;
-        const int o = ord++;
-        long long row;
-        if (n_out > 0) {
-            if (o % stride != 0) continue;
-            row = o / stride;
-            if (row >= n_out) continue;
-        } else {
-            row = o;
+    const long long pix0 = (long long)ch * UNP_CHUNK + wave * 1024;
+#pragma unroll 1
+    for (int it = 0; it < 16; ++it) {
+        // pixel it*64 + lane of the wave: bit (lane & 15) of word it*4 + lane/16
+        const unsigned word = __shfl(myword, it * 4 + (lane >> 4), 64);
+        const bool ok = (word >> (lane & 15)) & 1u;
+        const unsigned long long bal = __ballot(ok);
+        if (ok) {
+            const int rank = __popcll(bal & ((1ull << lane) - 1ull));
+            const long long row = (long long)b * cap + off + rank;
+            unp_emit(p, rgb, depth, pix0 + it * 64 + lane, out_points + row * 3, out_colors + row * 3);
         }
-        const long long i = base + k;
-        const int r = (int)(i % hw);
-        const int v = r / p.W, u = r % p.W;
-        const float zf = depth[i];
-        const double z = (double)zf;
-        const double xn = ((double)u - p.pp) / p.fx;          // pcm_tools.py:74
-        const double yn = ((double)v - p.pp) / p.fy;          // :75
-        double* op = out_points + ((long long)b * cap + row) * 3;
-        op[0] = xn * z;                                       // :77
-        op[1] = yn * z;
-        op[2] = z;
-        float* oc = out_colors + ((long long)b * cap + row) * 3;
-        const uint8_t* c = rgb + i * 3;
-        oc[0] = (float)c[0] / 255.0f;                         // :78 (float32 image / 255.0)
-        oc[1] = (float)c[1] / 255.0f;
-        oc[2] = (float)c[2] / 255.0f;
+        off += __popcll(bal);
     }
+}
+
+// (2b) subsample form (n_out > 0): one THREAD per output row j.  The row is valid pixel number j * stride of its sample
+// (stride = total / n_out): the block scans the sample's chunk counts once in LDS, each thread binary-searches its chunk,
+// walks that chunk's 256 mask words to the word holding its pixel and picks the bit.  O(n_out) work instead of a pass over
+// every chunk (44 us -> a few us at 16 x 448^2, B = 8).
+#define UNP_PICK_THREADS 1024
+__global__ __launch_bounds__(UNP_PICK_THREADS) void unp_pick_kernel(UnpParams p, const uint16_t* mask, const uint16_t* rank, const int32_t* chunk_cnt,
+                                                                    int32_t* out_count, int n_out, double* out_points, float* out_colors) {
+    extern __shared__ int pfx[];                               // inclusive prefix of the sample's chunk counts
+    __shared__ int wtot[UNP_PICK_THREADS / 64];
+    __shared__ int carry_s;
+    const int b = blockIdx.y;
+    const int32_t* cc = chunk_cnt + (long long)b * p.nchunks;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (int base = 0; base < p.nchunks; base += UNP_PICK_THREADS) {
+        const int i = base + threadIdx.x;
+        const int v = (i < p.nchunks) ? cc[i] : 0;
+        int x = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            int y = __shfl_up(x, o, 64);
+            if ((threadIdx.x & 63) >= o) x += y;
+        }
+        if ((threadIdx.x & 63) == 63) wtot[threadIdx.x >> 6] = x;
+        __syncthreads();
+        int woff = 0;
+        for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) woff += wtot[w];
+        const int carry = carry_s;
+        if (i < p.nchunks) pfx[i] = carry + woff + x;
+        __syncthreads();
+        if (threadIdx.x == UNP_PICK_THREADS - 1) carry_s = carry + woff + x;
+        __syncthreads();
+    }
+    const int total = carry_s;
+    if (blockIdx.x == 0 && threadIdx.x == 0) out_count[b] = total < n_out ? -total : total;
+    if (total < n_out) return;                                 // too few valid pixels for the subsample (caller checks the sign)
+    const int j = blockIdx.x * UNP_PICK_THREADS + threadIdx.x;
+    if (j >= n_out) return;
+    const int stride = total / n_out;
+    const int o = j * stride;                                  // ordinal of the pixel this row takes (< total)
+    int lo = 0, hi = p.nchunks - 1;                            // first chunk whose inclusive prefix exceeds o
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (pfx[mid] > o) hi = mid; else lo = mid + 1;
+    }
+    const int rem = o - (lo ? pfx[lo - 1] : 0);                // rank inside chunk lo
+    const long long cbase = (long long)b * p.nchunks * UNP_THREADS + (long long)lo * UNP_THREADS;
+    const uint16_t* rk = rank + cbase;
+    int wl = 0, wh = UNP_THREADS - 1;                          // last thread word whose exclusive rank is <= rem and that holds a pixel
+    while (wl < wh) {
+        const int mid = (wl + wh + 1) >> 1;
+        if ((int)rk[mid] <= rem) wl = mid; else wh = mid - 1;
+    }
+    // words with no valid pixel share the rank of their successor: the search lands on the LAST of them, which is the holder
+    unsigned word = mask[cbase + wl];
+    int r = rem - (int)rk[wl];
+    int bit = 0;
+    for (; bit < 16; ++bit) {
+        if ((word >> bit) & 1u) { if (r == 0) break; --r; }
+    }
+    const long long i = (long long)lo * UNP_CHUNK + (long long)wl * UNP_ITEMS + bit;
+    const long long row = (long long)b * n_out + j;
+    unp_emit(p, p.rgb + (long long)b * p.L * 3, p.depth + (long long)b * p.L, i, out_points + row * 3, out_colors + row * 3);
 }
 
 static inline int unp_nchunks(long long L) { return (int)((L + UNP_CHUNK - 1) / UNP_CHUNK); }
@@ -173,7 +231,7 @@ extern "C" size_t egomi_unproject_workspace_bytes(int B, int T, int H, int W) {
     const long long nch = unp_nchunks(L);
     size_t mask_bytes = (size_t)B * nch * UNP_THREADS * sizeof(uint16_t);
     mask_bytes = (mask_bytes + 255) & ~(size_t)255;
-    return mask_bytes + (size_t)B * nch * sizeof(int32_t);
+    return 2 * mask_bytes + (size_t)B * nch * sizeof(int32_t);       // validity words | in-chunk ranks | chunk counts
 }
 
 extern "C" int egomi_unproject_gather(const uint8_t* rgb, const float* depth, const int32_t* boxes, int n_boxes,
@@ -193,12 +251,17 @@ extern "C" int egomi_unproject_gather(const uint8_t* rgb, const float* depth, co
     p.nchunks = unp_nchunks(L);
     size_t mask_bytes = ((size_t)B * p.nchunks * UNP_THREADS * sizeof(uint16_t) + 255) & ~(size_t)255;
     uint16_t* mask = (uint16_t*)workspace;
-    int32_t* cnt = (int32_t*)((char*)workspace + mask_bytes);
+    uint16_t* rank = (uint16_t*)((char*)workspace + mask_bytes);
+    int32_t* cnt = (int32_t*)((char*)workspace + 2 * mask_bytes);
     hipStream_t s = (hipStream_t)stream;
     dim3 grid(p.nchunks, B);
-    EGOMI_LAUNCH(unp_mask_kernel, grid, dim3(UNP_THREADS), 0, s, p, mask, cnt);
-    const long long cap = n_out > 0 ? n_out : L;
-    EGOMI_LAUNCH(unp_write_kernel, grid, dim3(UNP_THREADS), 0, s, p, mask, cnt, out_count, n_out, cap, out_points, out_colors);
+    EGOMI_LAUNCH(unp_mask_kernel, grid, dim3(UNP_THREADS), 0, s, p, mask, rank, cnt);
+    if (n_out > 0 && (size_t)p.nchunks * sizeof(int) > 60 * 1024) return EGOMI_E_UNSUPPORTED;   // subsample form keeps the chunk prefix in LDS: <= 62.9 M pixels per sample
+    if (n_out > 0)
+        EGOMI_LAUNCH(unp_pick_kernel, dim3((n_out + UNP_PICK_THREADS - 1) / UNP_PICK_THREADS, B), dim3(UNP_PICK_THREADS), (size_t)p.nchunks * sizeof(int), s,
+                     p, mask, rank, cnt, out_count, n_out, out_points, out_colors);
+    else
+        EGOMI_LAUNCH(unp_write_dense_kernel, grid, dim3(UNP_THREADS), 0, s, p, mask, cnt, out_count, L, out_points, out_colors);
     return egomi_launch_status();
 }
 

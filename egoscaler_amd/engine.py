@@ -525,7 +525,13 @@ class Engine:
                 self._wgrad(Wn, g, x_in)
                 self._bgrad(bn, g)
                 if j > 0:
-                    g_in = ops.mm(g, w[Wn], out=ws.get(f"d_pp_act{j}", (B * Pn, w[Wn].shape[1]), T), b_layout=1)
+                    if T == torch.bfloat16:
+                        # dX = dY . W on the tuned K-contiguous kernel: the (trainable, hence changing) projector weight is
+                        # transposed on the fly (a 16-MB pass) instead of running the transposing generic kernel (0.34 ms each)
+                        wt = ops.transpose(w[Wn], out=ws.get(f"pp_wT{j}", (w[Wn].shape[1], w[Wn].shape[0]), T))
+                        g_in = ops.mm(g, wt, out=ws.get(f"d_pp_act{j}", (B * Pn, w[Wn].shape[1]), T))
+                    else:
+                        g_in = ops.mm(g, w[Wn], out=ws.get(f"d_pp_act{j}", (B * Pn, w[Wn].shape[1]), T), b_layout=1)
                     g = ops.gelu_bwd(g_in, acts[2 * j - 1], out=ws.get(f"d_pp_pre{j}", g_in.shape, T))
                 elif ctx.get("pb_ctx") is not None:
                     d_backbone = ops.mm(g, w[Wn], b_layout=1)                  # gradient w.r.t. the PointBERT output
