@@ -365,20 +365,28 @@ class TrajPointLLMForCausalLM(nn.Module):
         """model_arch.py:77-108: `max_length` means max_new_tokens; returns .sequences [B,S0+T] and
         .scores (T x [B,V]).  Prefill runs encoder + splice and fills the KV cache; every later step
         feeds one token (the behaviour pointllm.py:112,255-275 intends; see DESIGN.md on the
-        reference's cache bug).  do_sample=False is greedy arg-max and is what parity pins."""
-        if num_return_sequences != 1 or repetition_penalty != 1.0:
-            raise NotImplementedError("num_return_sequences != 1 / repetition_penalty are not built")
+        reference's cache bug).  do_sample=False is greedy arg-max and is what parity pins.  `repetition_penalty` and
+        `num_return_sequences` follow HF's logits processor / input expansion (model_arch.py:86-88 hands them through)."""
         from ..decode import Decoder, argmax_rows
         eng = self.engine
         dev = eng.device
         ids = input_ids.to(dev)
-        B, S0 = ids.shape
         if fps_start is None and point_clouds is not None:
-            fps_start = torch.randint(0, point_clouds.shape[1], (B,), dtype=torch.long)
+            fps_start = torch.randint(0, point_clouds.shape[1], (ids.shape[0],), dtype=torch.long)
+        n_ret = int(num_return_sequences)
+        if n_ret > 1:                                      # HF expands every input n times (generation/utils.py _expand_inputs_for_generation)
+            if isinstance(point_clouds, (list, tuple)):
+                raise NotImplementedError("num_return_sequences > 1 with a list of ragged clouds is not built")
+            ids = ids.repeat_interleave(n_ret, 0)
+            attention_mask = None if attention_mask is None else attention_mask.to(dev).repeat_interleave(n_ret, 0)
+            point_clouds = None if point_clouds is None else point_clouds.to(dev).repeat_interleave(n_ret, 0)
+            fps_start = None if fps_start is None else torch.as_tensor(fps_start).to(dev).repeat_interleave(n_ret, 0)
+        B, S0 = ids.shape
         T = int(max_length)
         dec = Decoder(eng, B, S0 + T)
         lg = dec.prefill(ids, attention_mask, point_clouds, fps_start, T)
-        if not do_sample and eos_token_id is None:
+        rp = float(repetition_penalty or 1.0)
+        if not do_sample and eos_token_id is None and rp == 1.0:
             # greedy, fixed length: all T steps captured into one hipGraph (use_graph) and replayed
             seq, scores = dec.greedy(T, use_graph=kwargs.get("use_graph", True))
             return GenerateOutput(sequences=seq, scores=tuple(scores))
@@ -386,6 +394,9 @@ class TrajPointLLMForCausalLM(nn.Module):
         done = torch.zeros(B, dtype=torch.bool, device=dev)
         for t in range(T):
             lgf = lg.float()
+            if rp != 1.0:                                  # HF RepetitionPenaltyLogitsProcessor: tokens already in the sequence
+                prev = torch.gather(lgf, 1, seq)
+                lgf = lgf.scatter(1, seq, torch.where(prev < 0, prev * rp, prev / rp))
             if do_sample:
                 s = lgf / max(float(temperature or 1.0), 1e-6)
                 if top_k:

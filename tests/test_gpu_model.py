@@ -111,6 +111,25 @@ def test_greedy_generate_matches_reference(tiny):
     assert o2.sequences.shape == (2, Lp + 3) and len(o2.scores) == 3
 
 
+def test_generate_repetition_penalty_and_num_return_sequences(tiny):
+    """model_arch.py:86-88 hands both to HF generate.  With greedy decoding: n return sequences are n copies of the single one;
+    penalty 1.0 is the identity; a penalty > 1 equals re-scoring the plain scores by HF's rule step by step."""
+    g, dims, toks, masks, Lp, pts = tiny
+    m = make_model(dims, False).eval()
+    kw = dict(input_ids=toks[:, :Lp].cuda(), attention_mask=masks[:, :Lp].cuda(), point_clouds=pts.cuda(), do_sample=False, fps_start=g["fps_start"])
+    base = m.generate(max_length=6, **kw)
+    o3 = m.generate(max_length=6, num_return_sequences=3, **kw)
+    assert o3.sequences.shape == (6, Lp + 6) and torch.equal(o3.sequences, base.sequences.repeat_interleave(3, 0))
+    pen = m.generate(max_length=6, repetition_penalty=1.3, **kw)
+    assert pen.sequences.shape == base.sequences.shape and len(pen.scores) == 6
+    # step 0: same model scores, penalised only at tokens present in the prompt
+    s0, p0 = base.scores[0], pen.scores[0]
+    seen = torch.zeros_like(s0, dtype=torch.bool).scatter(1, toks[:, :Lp].cuda(), True)
+    want = torch.where(seen, torch.where(s0 < 0, s0 * 1.3, s0 / 1.3), s0)
+    assert torch.allclose(p0, want, rtol=1e-5, atol=1e-6)
+    assert torch.equal(pen.sequences[:, Lp], p0.argmax(-1))
+
+
 def test_splice_errors_raise_like_reference(tiny):
     g, dims, toks, masks, Lp, pts = tiny
     m = make_model(dims, False).eval()
