@@ -56,7 +56,10 @@ const char* egomi_last_launch_error(void);
  *                cap = T*H*W rows reserved per sample; out_count[b] = n_valid
  *   n_out  > 0 : first-N strided subsample (stride = floor(n_valid / n_out), rows j*stride),
  *                cap = n_out; a sample with n_valid < n_out sets out_count[b] = -n_valid and its
- *                rows are left untouched (the host mirror raises ValueError)
+ *                rows are left untouched (the host mirror raises ValueError).  Up to 62.9 M pixels per sample in
+ *                this form (the chunk prefix lives in LDS); larger frames return EGOMI_E_UNSUPPORTED
+ * Two launches (validity bits + in-chunk ranks + chunk counts; then one thread per output row, or a coalesced
+ * dense writer): the workspace holds 2 x 2 B per 16 pixels + 4 B per 4096-pixel chunk per sample.
  */
 size_t egomi_unproject_workspace_bytes(int B, int T, int H, int W);
 int egomi_unproject_gather(const uint8_t* rgb, const float* depth, const int32_t* boxes, int n_boxes,
