@@ -280,16 +280,20 @@ extern "C" int egomi_rope(void* x, const float* cos_tab, const float* sin_tab, i
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
 
+// il = 1: gate and up are the two halves of every 64-column group of ONE [rows, 2*cols] array ("interleaved-32": hidden
+// unit c lives at column 64*(c/32) + c%32, its up value 32 columns further) — the layout the stacked [Wgate;Wup] weight of
+// the frozen layers produces, chosen so that one GEMM wave holds gate and up of the same units (fused epilogue, gemm_fast.hip)
 template <typename T>
-__global__ __launch_bounds__(256) void swiglu_fwd_kernel(const T* gate, const T* up, T* out, long long rows, int cols, long long ld_in, long long ld_out) {
+__global__ __launch_bounds__(256) void swiglu_fwd_kernel(const T* gate, const T* up, T* out, long long rows, int cols, long long ld_in, long long ld_out, int il) {
     const int cv = cols / 8;
     const long long total = rows * cv;
     for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
         const long long r = e / cv;
         const int c = (int)(e % cv) * 8;
+        const int ci = il ? ((c >> 5) << 6) + (c & 31) : c;
         float g[8], u[8], o[8];
-        load8<T>(gate + r * ld_in + c, g);
-        load8<T>(up + r * ld_in + c, u);
+        load8<T>(gate + r * ld_in + ci, g);
+        load8<T>(up + r * ld_in + ci, u);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             float a = g[j] * sigmoidf_(g[j]);
@@ -302,24 +306,25 @@ __global__ __launch_bounds__(256) void swiglu_fwd_kernel(const T* gate, const T*
 
 template <typename T>
 __global__ __launch_bounds__(256) void swiglu_bwd_kernel(const T* dact, const T* gate, const T* up, T* dgate, T* dup, long long rows, int cols,
-                                                         long long ld_in, long long ld_act, long long ld_out) {
+                                                         long long ld_in, long long ld_act, long long ld_out, int il) {
     const int cv = cols / 8;
     const long long total = rows * cv;
     for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
         const long long r = e / cv;
         const int c = (int)(e % cv) * 8;
+        const int ci = il ? ((c >> 5) << 6) + (c & 31) : c;
         float d[8], g[8], u[8], og[8], ou[8];
         load8<T>(dact + r * ld_act + c, d);
-        load8<T>(gate + r * ld_in + c, g);
-        load8<T>(up + r * ld_in + c, u);
+        load8<T>(gate + r * ld_in + ci, g);
+        load8<T>(up + r * ld_in + ci, u);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const float sg = sigmoidf_(g[j]);
             ou[j] = d[j] * g[j] * sg;
             og[j] = d[j] * u[j] * sg * (1.0f + g[j] * (1.0f - sg));
         }
-        store8<T>(dgate + r * ld_out + c, og);
-        store8<T>(dup + r * ld_out + c, ou);
+        store8<T>(dgate + r * ld_out + ci, og);
+        store8<T>(dup + r * ld_out + ci, ou);
     }
 }
 
@@ -330,7 +335,7 @@ extern "C" int egomi_swiglu_fwd(const void* gate, const void* up, void* out, int
     if (!gate || !up || !out) return EGOMI_E_BADARG;
     if (rows <= 0 || cols <= 0 || cols % 8 || ld_in % 8 || ld_out % 8 || ld_in < cols || ld_out < cols) return EGOMI_E_SHAPE;
     EGOMI_DISPATCH_DTYPE(dtype, EGOMI_LAUNCH(swiglu_fwd_kernel<T>, dim3(ew_grid(rows * (cols / 8))), dim3(256), 0, (hipStream_t)stream,
-                                                   (const T*)gate, (const T*)up, (T*)out, rows, cols, ld_in, ld_out));
+                                                   (const T*)gate, (const T*)up, (T*)out, rows, cols, ld_in, ld_out, 0));
     return egomi_launch_status();
 }
 
@@ -339,7 +344,24 @@ extern "C" int egomi_swiglu_bwd(const void* dact, const void* gate, const void* 
     if (!dact || !gate || !up || !dgate || !dup) return EGOMI_E_BADARG;
     if (rows <= 0 || cols <= 0 || cols % 8 || ld_in % 8 || ld_act % 8 || ld_out % 8) return EGOMI_E_SHAPE;
     EGOMI_DISPATCH_DTYPE(dtype, EGOMI_LAUNCH(swiglu_bwd_kernel<T>, dim3(ew_grid(rows * (cols / 8))), dim3(256), 0, (hipStream_t)stream,
-                                                   (const T*)dact, (const T*)gate, (const T*)up, (T*)dgate, (T*)dup, rows, cols, ld_in, ld_act, ld_out));
+                                                   (const T*)dact, (const T*)gate, (const T*)up, (T*)dgate, (T*)dup, rows, cols, ld_in, ld_act, ld_out, 0));
+    return egomi_launch_status();
+}
+
+// interleaved-32 forms: gu / dgu are [rows, 2*cols] with hidden unit c at column 64*(c/32) + c%32 (gate) and +32 (up)
+extern "C" int egomi_swiglu_il_fwd(const void* gu, void* out, int64_t rows, int cols, int64_t ld_gu, int64_t ld_out, int dtype, egomi_stream_t stream) {
+    if (!gu || !out) return EGOMI_E_BADARG;
+    if (rows <= 0 || cols <= 0 || cols % 32 || ld_gu % 8 || ld_out % 8 || ld_gu < 2 * cols || ld_out < cols) return EGOMI_E_SHAPE;
+    EGOMI_DISPATCH_DTYPE(dtype, EGOMI_LAUNCH(swiglu_fwd_kernel<T>, dim3(ew_grid(rows * (cols / 8))), dim3(256), 0, (hipStream_t)stream,
+                                                   (const T*)gu, (const T*)gu + 32, (T*)out, rows, cols, ld_gu, ld_out, 1));
+    return egomi_launch_status();
+}
+extern "C" int egomi_swiglu_il_bwd(const void* dact, const void* gu, void* dgu, int64_t rows, int cols, int64_t ld_gu, int64_t ld_act, int64_t ld_dgu,
+                                   int dtype, egomi_stream_t stream) {
+    if (!dact || !gu || !dgu) return EGOMI_E_BADARG;
+    if (rows <= 0 || cols <= 0 || cols % 32 || ld_gu % 8 || ld_act % 8 || ld_dgu % 8 || ld_gu < 2 * cols || ld_dgu < 2 * cols) return EGOMI_E_SHAPE;
+    EGOMI_DISPATCH_DTYPE(dtype, EGOMI_LAUNCH(swiglu_bwd_kernel<T>, dim3(ew_grid(rows * (cols / 8))), dim3(256), 0, (hipStream_t)stream,
+                                                   (const T*)dact, (const T*)gu, (const T*)gu + 32, (T*)dgu, (T*)dgu + 32, rows, cols, ld_gu, ld_act, ld_dgu, 1));
     return egomi_launch_status();
 }
 

@@ -33,6 +33,7 @@ struct FastArgs {
     int tiles_m, tiles_n;
     int splitk; float* ws;           // splitk > 1: block (tile, blockIdx.y) multiplies its K slice and stores a raw fp32 slab
     int full_tm, full_tiles, tail_s; // 8-phase kernel: M-tile rows >= full_tm are cut into tail_s K-slices (fp32 slabs of those rows only)
+    int epi; void* C2; long long ldc2;   // epi 1 (EGOMI_EPI_SWIGLU): C is interleaved-32 gate|up, C2 [M, N/2] receives silu(gate)*up (bf16 only)
     int* tickets;                    // non-null: the K-slices of a tail tile are summed INSIDE the launch by the slice block that arrives last
                                      // (one ticket word per tail tile, zero on entry, returned to zero); ws then holds register-major slabs
 };
@@ -481,6 +482,37 @@ void gemm_nt_bf16_8phase_kernel(FastArgs g) {
                 const int m = mb + pass * 64 + r;
                 if (m < g.M) *reinterpret_cast<u32x4*>(C + (long long)m * g.ldc + nb + ch * 8) = v;
             }
+            if (g.epi == 1) {
+                // SwiGLU in the epilogue (HF LlamaMLP, modeling_llama.py:174-176): the wave's 64 columns are one interleaved-32 group,
+                // gate in accumulators j = 0,1 and up of the SAME 32 hidden units in j = 2,3, so silu(gate)*up is lane-local.  Rounding
+                // sequence of swiglu_fwd_kernel on the stored bf16 values (bit-identical to the unfused path): g, u rounded to bf16,
+                // a = bf16(g*sigmoid(g)), out = bf16(a*u).  Rows leave as 64-B segments through the same strip.
+                bf16_t* C2 = reinterpret_cast<bf16_t*>(g.C2);
+#pragma unroll
+                for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const f32x4 vg = acc[j][4 * pass + ii], vu = acc[j + 2][4 * pass + ii];
+                        float o4[4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float gg = bf2f(f2bf(vg[r])), uu = bf2f(f2bf(vu[r]));
+                            const float a = bf2f(f2bf(gg * (1.0f / (1.0f + __expf(-gg)))));
+                            o4[r] = a * uu;
+                        }
+                        u32x2 o;
+                        o[0] = (uint32_t)f2bf(o4[0]) | ((uint32_t)f2bf(o4[1]) << 16);
+                        o[1] = (uint32_t)f2bf(o4[2]) | ((uint32_t)f2bf(o4[3]) << 16);
+                        *reinterpret_cast<u32x2*>(wb + (ii * 16 + (lane & 15)) * 144 + (j * 16 + (lane >> 4) * 4) * 2) = o;
+                    }
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const int r = it * 16 + (lane >> 2), ch = lane & 3;
+                    const u32x4 v = *reinterpret_cast<const u32x4*>(wb + r * 144 + ch * 16);
+                    const int m = mb + pass * 64 + r;
+                    if (m < g.M) *reinterpret_cast<u32x4*>(C2 + (long long)m * g.ldc2 + (nb >> 1) + ch * 8) = v;
+                }
+            }
         }
         return;
     }
@@ -845,7 +877,6 @@ static int tile_choice(const egomi_gemm_desc* d) {
     return (d->M >= 2048 && d->N >= 8192) ? 2 : 1;
 }
 
-static bool p8_applicable(const egomi_gemm_desc* d, struct P8Sched& sc);
 extern "C" int egomi_gemm_kernel_id(const egomi_gemm_desc* d) {
     if (!d) return EGOMI_E_BADARG;
     if (d->force_generic || !fast_applicable(d)) return 0;
@@ -1008,6 +1039,7 @@ static int launch_8phase(const egomi_gemm_desc* d, FastArgs& g, hipStream_t s, i
     if (d->c_dtype == EGOMI_BF16) EGOMI_LAUNCH(gemm_nt_bf16_8phase_kernel<bf16_t>, dim3(nwg, 1), dim3(512), 0, s, g);
     else if (d->c_dtype == EGOMI_F32) EGOMI_LAUNCH(gemm_nt_bf16_8phase_kernel<float>, dim3(nwg, 1), dim3(512), 0, s, g);
     else return EGOMI_E_UNSUPPORTED;
+    if (tp.rows && g.epi == 1 && g.tickets) g.tickets = nullptr;         // the fused SwiGLU epilogue wants the separate combine + tail pass below
     if (tp.rows && !g.tickets) {
         FastArgs r = g;
         const long long row0 = (long long)g.full_tm * 256;
@@ -1019,6 +1051,10 @@ static int launch_8phase(const egomi_gemm_desc* d, FastArgs& g, hipStream_t s, i
         const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
         if (d->c_dtype == EGOMI_BF16) EGOMI_LAUNCH(splitk_reduce_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, r);
         else EGOMI_LAUNCH(splitk_reduce_kernel<float>, dim3(grid), dim3(256), 0, s, r);
+        if (g.epi == 1) {                                              // K-sliced tail rows: gate|up just combined, SwiGLU on those rows only
+            const int rc = egomi_swiglu_il_fwd(r.C, (char*)g.C2 + row0 * g.ldc2 * 2, r.M, d->N / 2, g.ldc, g.ldc2, EGOMI_BF16, (egomi_stream_t)s);
+            if (rc != EGOMI_OK) return rc;
+        }
     }
     return egomi_launch_status();
 }
@@ -1032,7 +1068,21 @@ int egomi_gemm_fast_try(const egomi_gemm_desc* d0, hipStream_t s) {
     g.A = (const bf16_t*)d->A; g.B = (const bf16_t*)d->B; g.C = d->C; g.bias = (const bf16_t*)d->bias; g.residual = d->residual;
     g.M = d->M; g.N = d->N; g.K = d->K; g.lda = d->lda; g.ldb = d->ldb; g.ldc = d->ldc; g.ldr = d->ldr;
     g.alpha = d->alpha; g.accumulate = d->accumulate; g.act = d->act; g.tickets = nullptr;
+    g.epi = d->epilogue; g.C2 = d->C2; g.ldc2 = d->ldc2;
     const int tc = tile_choice(d);
+    if (d->epilogue != EGOMI_EPI_NONE) {
+        // fused epilogues live in the 256x256 per-tile kernel's plain-bf16 store path only: whole interleaved groups per wave
+        // (N % 256 == 0), 16-B aligned rows, nothing else in the epilogue
+        const bool ok = d->epilogue == EGOMI_EPI_SWIGLU && tc == 8 && d->c_dtype == EGOMI_BF16 && d->C2 && d->N % 256 == 0 && !d->bias && !d->residual &&
+                        !d->accumulate && d->act == 0 && d->alpha == 1.0f && d->ldc % 8 == 0 && d->ldc2 % 8 == 0 && d->ldc2 >= d->N / 2 &&
+                        (((uintptr_t)d->C | (uintptr_t)d->C2) & 15) == 0 && (long long)d->M * d->lda < (1ll << 31) && (long long)d->N * d->ldb < (1ll << 31);
+        if (!ok) return EGOMI_E_UNSUPPORTED;
+        if (dl.ws_tickets_zeroed && dl.workspace) {
+            if (dl.workspace_bytes > 4096) { dl.workspace = (char*)dl.workspace + 4096; dl.workspace_bytes -= 4096; }
+            else { dl.workspace = nullptr; dl.workspace_bytes = 0; }
+        }
+        return launch_8phase(d, g, s, nullptr);
+    }
     if (tc == 8 && (long long)d->M * d->lda < (1ll << 31) && (long long)d->N * d->ldb < (1ll << 31)) {
         P8Sched sc;
         if (p8_applicable(d, sc)) return launch_p8(d, g, sc, s);

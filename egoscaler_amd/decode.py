@@ -55,8 +55,8 @@ class Decoder:
             engine.prepare()
         self.wqkv = [engine.wqkv[l] if l in engine.wqkv else torch.cat([w[f"model.layers.{l}.self_attn.{n}_proj.weight"] for n in "qkv"], 0)
                      for l in range(L)]
-        self.wgu = [engine.wgu[l] if l in engine.wgu else torch.cat([w[f"model.layers.{l}.mlp.{n}_proj.weight"] for n in ("gate", "up")], 0)
-                    for l in range(L)]
+        self.wgu = [engine.wgu[l] if l in engine.wgu else engine.stack_gate_up(w[f"model.layers.{l}.mlp.gate_proj.weight"], w[f"model.layers.{l}.mlp.up_proj.weight"])
+                    for l in range(L)]                     # interleaved-32 rows when ffn % 32 == 0 (engine.gu_il): gate|up come out interleaved
 
     # -- prefill -------------------------------------------------------------------------------------
     def _sink(self, l, qkv, B, Sq):
@@ -121,7 +121,10 @@ class Decoder:
             ops.mm(self.ao, w[p + "self_attn.o_proj.weight"], out=self.x_mid, residual=x, workspace=self.gws)
             ops.rmsnorm(self.x_mid, w[p + "post_attention_layernorm.weight"], lm.rms_norm_eps, out=self.h2)
             ops.mm(self.h2, self.wgu[l], out=self.gu, workspace=self.gws)
-            ops.swiglu(self.gu[:, :Fd], self.gu[:, Fd:], self.act)
+            if eng.gu_il:
+                ops.swiglu_il(self.gu, self.act)
+            else:
+                ops.swiglu(self.gu[:, :Fd], self.gu[:, Fd:], self.act)
             ops.mm(self.act, w[p + "mlp.down_proj.weight"], out=x, residual=self.x_mid, workspace=self.gws)     # x is not an input of this product
         ops.rmsnorm(x, w["model.norm.weight"], lm.rms_norm_eps, out=self.hn)
         ops.mm(self.hn, w["lm_head.weight"], out=self.lg)

@@ -10,6 +10,7 @@ Reference call stack this replaces:
   HF modeling_llama.py:367-418        LlamaModel.forward (32 decoder layers)
   pointllm/model/pointllm.py:227-228  lm_head ;  train.py:174-184  loss, backward
 """
+import os
 from typing import Dict
 
 import torch
@@ -57,6 +58,8 @@ class Engine:
         self.ctx = None
         self.grad_sync = None          # optional dp.GradSync: notified when a gradient buffer is final
         self.use_fused_attention = True
+        self.use_fused_swiglu = os.environ.get("EGOMI_NO_FUSED_SWIGLU", "0") != "1"   # SwiGLU in the gate|up GEMM epilogue where the 256x256
+                                                                                      # kernel runs (tests and A/B runs switch it off)
         self.pb_trainer = None
         self.pb_train_mode = False          # set by TrajPointLLMForCausalLM.train(): point backbone in train() mode
         self.prepared_bn_stale = False
@@ -106,18 +109,30 @@ class Engine:
                     self.wqkv[l] = torch.cat([w[p + f"{n}_proj.weight"] for n in "qkv"], 0)
         # ... and [Wgate;Wup] for the forward, [WqT|WkT|WvT] / [WgateT|WupT] (K-concatenated) for dgrad: one long-K product
         # per block instead of 2-3 read-modify-write passes over dX; their separate W^T copies are dropped
+        # [Wgate;Wup] is stacked with its rows INTERLEAVED in blocks of 32 (ffn % 32 == 0): gate|up then come out of the product in
+        # the interleaved-32 layout (hidden unit c at column 64*(c/32) + c%32, up 32 further), in which one GEMM wave holds gate and
+        # up of the same units, so silu(gate)*up is computed in the GEMM epilogue (EGOMI_EPI_SWIGLU) instead of a separate pass
         self.wgu, self.wqkvT, self.wguT = {}, {}, {}
+        self.gu_il = lm.intermediate_size % 32 == 0
         if self.dtype == torch.bfloat16:
             for l in range(lm.num_hidden_layers):
                 pa, pm = f"model.layers.{l}.self_attn.", f"model.layers.{l}.mlp."
                 if l in self.wqkv:
                     self.wqkvT[l] = torch.cat([self.wT.pop(pa + f"{n}_proj.weight") for n in "qkv"], 1)
                 if not any((pm + f"{n}_proj.weight") in self.trainable for n in ("gate", "up")):
-                    self.wgu[l] = torch.cat([w[pm + "gate_proj.weight"], w[pm + "up_proj.weight"]], 0)
-                    self.wguT[l] = torch.cat([self.wT.pop(pm + "gate_proj.weight"), self.wT.pop(pm + "up_proj.weight")], 1)
+                    self.wgu[l] = self.stack_gate_up(w[pm + "gate_proj.weight"], w[pm + "up_proj.weight"])
+                    self.wT.pop(pm + "gate_proj.weight"), self.wT.pop(pm + "up_proj.weight")
+                    self.wguT[l] = ops.transpose(self.wgu[l])
         cos, sin = ops.rope_tables(lm.max_position_embeddings, lm.head_dim, lm.rope_theta)
         self.cos, self.sin = cos.to(self.device), sin.to(self.device)
         self.prepared = True
+
+    def stack_gate_up(self, gate, up):
+        """[Wgate;Wup] -> [2*ffn, d]; rows interleaved in blocks of 32 when ffn allows (self.gu_il), plain concatenation otherwise."""
+        if not self.gu_il:
+            return torch.cat([gate, up], 0)
+        Fd = gate.shape[0]
+        return torch.stack([gate.view(Fd // 32, 32, -1), up.view(Fd // 32, 32, -1)], 1).reshape(2 * Fd, -1).contiguous()
 
     def after_weights_update(self):
         """Called by the optimizer after a step: the resident W^T of TRAINABLE decoder weights must
@@ -338,6 +353,7 @@ class Engine:
             key_mask = attention_mask.to(device=self.device, dtype=torch.uint8).contiguous()
         scale = hd ** -0.5
         fused = self.use_fused_attention and T == torch.bfloat16 and hd == 128
+        fuse_swiglu = self.use_fused_swiglu and T == torch.bfloat16 and self.gu_il and (2 * Fd) % 256 == 0 and ops.gemm_kernel_id(M, 2 * Fd, d) == 2
         for l in range(L):
             p = f"model.layers.{l}."
             if save:
@@ -377,12 +393,19 @@ class Engine:
                 Pm = self._attention(qkv, B, S, H, hd, ao, True, key_mask, scale, save)
             ops.mm(ao, w[p + "self_attn.o_proj.weight"], out=x_mid, residual=x)
             ops.rmsnorm(x_mid, w[p + "post_attention_layernorm.weight"], lm.rms_norm_eps, rstd=rstd2, out=h2)
-            if l in self.wgu:
-                ops.mm(h2, self.wgu[l], out=gu)
+            if l in self.wgu and self.gu_il:
+                if fuse_swiglu:
+                    ops.mm(h2, self.wgu[l], out=gu, swiglu_out=act)          # act leaves the GEMM epilogue; gu (interleaved-32) is kept for backward
+                else:
+                    ops.mm(h2, self.wgu[l], out=gu)
+                    ops.swiglu_il(gu, act)
             else:
-                ops.mm(h2, w[p + "mlp.gate_proj.weight"], out=gu[:, :Fd])
-                ops.mm(h2, w[p + "mlp.up_proj.weight"], out=gu[:, Fd:])
-            ops.swiglu(gu[:, :Fd], gu[:, Fd:], act)
+                if l in self.wgu:
+                    ops.mm(h2, self.wgu[l], out=gu)
+                else:
+                    ops.mm(h2, w[p + "mlp.gate_proj.weight"], out=gu[:, :Fd])
+                    ops.mm(h2, w[p + "mlp.up_proj.weight"], out=gu[:, Fd:])
+                ops.swiglu(gu[:, :Fd], gu[:, Fd:], act)
             ops.mm(act, w[p + "mlp.down_proj.weight"], out=x_out, residual=x_mid)
             if save:
                 lc.update(P=Pm, lse=lse, x_mid=x_mid, h=h, ao=ao, h2=h2, act=act)
@@ -474,7 +497,10 @@ class Engine:
             d_act = self._dgrad(dx, p + "mlp.down_proj.weight", ws.get("d_act", (M, Fd), T))
             self._wgrad(p + "mlp.down_proj.weight", dx, lc["act"])
             dgu = ws.get("dgu", (M, 2 * Fd), T)
-            ops.swiglu_bwd(d_act, gu[:, :Fd], gu[:, Fd:], dgu[:, :Fd], dgu[:, Fd:])
+            if self.prepared and l in self.wguT and self.gu_il:
+                ops.swiglu_il_bwd(d_act, gu, dgu)                               # gu / dgu in the interleaved-32 layout of the stacked weight
+            else:
+                ops.swiglu_bwd(d_act, gu[:, :Fd], gu[:, Fd:], dgu[:, :Fd], dgu[:, Fd:])
             if self.prepared and l in self.wguT:
                 d_h2 = ops.mm(dgu, self.wguT[l], out=ws.get("d_h", (M, d), T))
             else:

@@ -130,7 +130,8 @@ class GemmDesc(ctypes.Structure):
                 ("batch", c_i), ("batch_inner", c_i),
                 ("sA0", c_i64), ("sA1", c_i64), ("sB0", c_i64), ("sB1", c_i64), ("sC0", c_i64), ("sC1", c_i64),
                 ("alpha", c_f), ("accumulate", c_i), ("act", c_i), ("force_generic", c_i),
-                ("workspace", c_p), ("workspace_bytes", c_i64), ("split_k", c_i), ("ws_tickets_zeroed", c_i)]
+                ("workspace", c_p), ("workspace_bytes", c_i64), ("split_k", c_i), ("ws_tickets_zeroed", c_i),
+                ("epilogue", c_i), ("C2", c_p), ("ldc2", c_i64)]
 
 
 ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
@@ -171,7 +172,7 @@ def _tail_workspace(device, nbytes=(4096 + 256 * 2 * 262144)):
 
 def gemm_raw(A, B, C, M, N, K, lda, ldb, ldc, a_layout=0, b_layout=0, bias=None, residual=None, ldr=0,
              act=0, alpha=1.0, accumulate=False, batch=1, batch_inner=1, strides=(0, 0, 0, 0, 0, 0), force_generic=False,
-             workspace=None, split_k=0, persistent=None):
+             workspace=None, split_k=0, persistent=None, swiglu_out=None):
     """C = act(alpha*A.B + bias) + residual (+C).  A/B/C are tensors whose data_ptr() is the first
     element of the (first) operand; all strides in elements.  See include/egomi.h."""
     if A.dtype != B.dtype:
@@ -191,6 +192,8 @@ def gemm_raw(A, B, C, M, N, K, lda, ldb, ldc, a_layout=0, b_layout=0, bias=None,
     d.batch, d.batch_inner = batch, batch_inner
     d.sA0, d.sA1, d.sB0, d.sB1, d.sC0, d.sC1 = strides
     d.alpha, d.accumulate, d.act, d.force_generic = alpha, int(accumulate), act, int(force_generic)
+    if swiglu_out is not None:                            # EGOMI_EPI_SWIGLU: C = interleaved-32 gate|up, swiglu_out [M, N/2] = silu(gate)*up
+        d.epilogue, d.C2, d.ldc2 = 1, swiglu_out.data_ptr(), _ld(swiglu_out)
     if workspace is None and M >= 1024 and batch <= 1:
         workspace = _tail_workspace(A.device)            # ticket words + fp32 slabs for the shared tiles of the 256x256 kernel
         if persistent is False:                          # A/B runs, tests: the non-persistent kernel + combine launch; its slabs must
@@ -274,6 +277,28 @@ def swiglu(gate, up, out):
     rows, cols = gate.shape
     call("egomi_swiglu_fwd", P(gate), P(up), P(out), c_i64(rows), c_i(cols), c_i64(_ld(gate)), c_i64(_ld(out)), c_i(dt(gate.dtype)), S())
     return out
+
+
+def swiglu_il(gu, out):
+    """Interleaved-32 gate|up array gu [rows, 2*cols] -> out [rows, cols] = silu(gate)*up."""
+    rows, cols = out.shape
+    call("egomi_swiglu_il_fwd", P(gu), P(out), c_i64(rows), c_i(cols), c_i64(_ld(gu)), c_i64(_ld(out)), c_i(dt(gu.dtype)), S())
+    return out
+
+
+def swiglu_il_bwd(dact, gu, dgu):
+    rows, cols = dact.shape
+    call("egomi_swiglu_il_bwd", P(dact), P(gu), P(dgu), c_i64(rows), c_i(cols), c_i64(_ld(gu)), c_i64(_ld(dact)), c_i64(_ld(dgu)), c_i(dt(gu.dtype)), S())
+    return dgu
+
+
+def gemm_kernel_id(M, N, K, dtype=torch.bfloat16, out_dtype=torch.bfloat16):
+    """Which kernel egomi_gemm would pick for a plain contiguous NT product of this shape (2 = 256x256 8-phase)."""
+    d = GemmDesc()
+    d.A = d.B = d.C = 256                                 # aligned placeholders: the selection looks at shapes and alignment only
+    d.M, d.N, d.K, d.lda, d.ldb, d.ldc = M, N, K, K, K, N
+    d.ab_dtype, d.c_dtype, d.batch = dt(dtype), dt(out_dtype), 1
+    return _lib.lib().egomi_gemm_kernel_id(ctypes.byref(d))
 
 
 def swiglu_bwd(dact, gate, up, dgate, dup):

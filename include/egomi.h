@@ -138,7 +138,16 @@ typedef struct egomi_gemm_desc {
      * kernel: with weights cold from HBM the persistent form measured 5 % slower in the training step, csrc/gemm_fast.hip);
      * 2: the promise is made and the persistent form is taken for every shape it can run.  0: no promise. */
     int ws_tickets_zeroed;
+    /* fused epilogue.  EGOMI_EPI_SWIGLU: B is [Wgate;Wup] stacked with its rows interleaved in blocks of 32 (row 64g+c =
+     * Wgate[32g+c], row 64g+32+c = Wup[32g+c]); C [M,N] receives gate|up in that interleaved-32 layout (kept for backward)
+     * and C2 [M, N/2] (row stride ldc2) receives silu(gate)*up = what egomi_swiglu_il_fwd(C) would write, bit for bit
+     * (replaces the separate pass over C of HF LlamaMLP.forward, modeling_llama.py:174-176).  bf16 output, N % 256 == 0, no
+     * bias / residual / activation / alpha / accumulate, products large enough for the 256x256 kernel
+     * (egomi_gemm_kernel_id == 2); anything else returns EGOMI_E_UNSUPPORTED. */
+    int epilogue; void* C2; int64_t ldc2;
 } egomi_gemm_desc;
+#define EGOMI_EPI_NONE 0
+#define EGOMI_EPI_SWIGLU 1
 int egomi_gemm(const egomi_gemm_desc* desc, egomi_stream_t stream);
 /* which kernel egomi_gemm would run for this descriptor: 2 = 256x256 8-phase bf16 NT kernel (either form), 1 = 128x128 / 256x128 bf16
  * NT kernel, 0 = generic */
@@ -269,6 +278,13 @@ int egomi_swiglu_fwd(const void* gate, const void* up, void* out, int64_t rows, 
                      int dtype, egomi_stream_t stream);
 int egomi_swiglu_bwd(const void* dact, const void* gate, const void* up, void* dgate, void* dup, int64_t rows, int cols,
                      int64_t ld_in, int64_t ld_act, int64_t ld_out, int dtype, egomi_stream_t stream);
+/* The same two ops on the "interleaved-32" gate|up layout: gu / dgu are ONE [rows, 2*cols] array in which hidden unit c
+ * sits at column 64*(c/32) + c%32 (gate) and 32 columns further (up).  It is what x . [Wgate;Wup]^T yields when the rows of
+ * the stacked weight are interleaved in blocks of 32, which puts gate and up of the same units into the same GEMM wave
+ * (egomi_gemm epilogue EGOMI_EPI_SWIGLU).  cols % 32 == 0. */
+int egomi_swiglu_il_fwd(const void* gu, void* out, int64_t rows, int cols, int64_t ld_gu, int64_t ld_out, int dtype, egomi_stream_t stream);
+int egomi_swiglu_il_bwd(const void* dact, const void* gu, void* dgu, int64_t rows, int cols, int64_t ld_gu, int64_t ld_act, int64_t ld_dgu,
+                        int dtype, egomi_stream_t stream);
 
 /* exact (erf) GELU and its derivative.  replaces nn.GELU in point_proj, model/pointllm.py:72-76 */
 int egomi_gelu_fwd(const void* x, void* y, int64_t n, int dtype, egomi_stream_t stream);

@@ -397,6 +397,52 @@ def test_gemm_persistent_8phase_kernel(ops, M, N, K):
     assert int(ops._tail_workspace(A.device)[:1024].view(torch.int32).abs().max()) == 0
 
 
+def _interleave32(gate, up):
+    Fd = gate.shape[-1]
+    return torch.stack([gate.reshape(*gate.shape[:-1], Fd // 32, 32), up.reshape(*up.shape[:-1], Fd // 32, 32)], -2).reshape(*gate.shape[:-1], 2 * Fd)
+
+
+def test_swiglu_interleaved32_layout(ops):
+    """egomi_swiglu_il_fwd / _bwd on the interleaved-32 gate|up layout == the plain kernels on the de-interleaved halves, bit for bit."""
+    M, Fd = 300, 352
+    gate, up, dact = rnd(M, Fd, dtype=torch.bfloat16, seed=41).cuda(), rnd(M, Fd, dtype=torch.bfloat16, seed=42).cuda(), rnd(M, Fd, dtype=torch.bfloat16, seed=43).cuda()
+    gu = _interleave32(gate, up).contiguous()
+    ref = torch.empty(M, Fd, dtype=torch.bfloat16, device="cuda")
+    ops.swiglu(gate, up, ref)
+    got = ops.swiglu_il(gu, torch.empty_like(ref))
+    assert torch.equal(got, ref)
+    close(got, F.silu(gate.float().cpu()) * up.float().cpu(), 1e-2)
+    dg, du = torch.empty_like(gate), torch.empty_like(up)
+    ops.swiglu_bwd(dact, gate, up, dg, du)
+    dgu = ops.swiglu_il_bwd(dact, gu, torch.empty_like(gu))
+    assert torch.equal(dgu, _interleave32(dg, du))
+
+
+@pytest.mark.parametrize("M,Fd,K", [(5536, 11008, 4096), (5000, 2048, 2048), (2304, 8192, 2112)])
+def test_gemm_swiglu_epilogue(ops, M, Fd, K):
+    """EGOMI_EPI_SWIGLU: x . [Wgate;Wup]^T with the stacked rows interleaved in blocks of 32 — C (gate|up, interleaved-32) equals
+    the plain product and C2 equals egomi_swiglu_il_fwd(C) bit for bit, on whole tiles, ragged M and K-sliced tail rows; shapes
+    the fused path cannot serve are refused, never silently computed without C2."""
+    from egoscaler_amd import _lib
+    x = rnd(M, K, dtype=torch.bfloat16, seed=51).cuda()
+    wg, wu = rnd(Fd, K, dtype=torch.bfloat16, seed=52, scale=0.05).cuda(), rnd(Fd, K, dtype=torch.bfloat16, seed=53, scale=0.05).cuda()
+    w = torch.stack([wg.view(Fd // 32, 32, K), wu.view(Fd // 32, 32, K)], 1).reshape(2 * Fd, K).contiguous()
+    assert ops.gemm_kernel_id(M, 2 * Fd, K) == 2
+    gu_ref = ops.mm(x, w)
+    act_ref = ops.swiglu_il(gu_ref, torch.empty(M, Fd, dtype=torch.bfloat16, device="cuda"))
+    gu = torch.empty_like(gu_ref)
+    act = torch.full((M, Fd), 7.0, dtype=torch.bfloat16, device="cuda")
+    ops.mm(x, w, out=gu, swiglu_out=act)
+    assert torch.equal(gu, gu_ref)
+    assert torch.equal(act, act_ref)
+    g32, u32 = x.float() @ wg.float().t(), x.float() @ wu.float().t()
+    close(act, (F.silu(g32) * u32).cpu(), 2e-2)                                    # and it is the right function of the operands
+    with pytest.raises(_lib.EgomiError):
+        ops.mm(x[:64], w, out=gu[:64], swiglu_out=act[:64])                          # too small for the 256x256 kernel
+    with pytest.raises(_lib.EgomiError):
+        ops.mm(x, w, out=gu, swiglu_out=act, bias=torch.zeros(2 * Fd, dtype=torch.bfloat16, device="cuda"))
+
+
 def _ref_attention(qkv, B, S, H, hd, scale, causal, km):
     x = qkv.float().view(B, S, 3, H, hd)
     q, k, v = x[:, :, 0].transpose(1, 2), x[:, :, 1].transpose(1, 2), x[:, :, 2].transpose(1, 2)

@@ -132,6 +132,22 @@ def test_bf16_7b_width_step_matches_fp32_oracle(wide, unfreeze):
           + "; ".join(f"{n.replace('model.', '')}: {e[0]:.1e}/{e[1]:.1e}" for n, e in report.items()))
 
 
+def test_bf16_7b_width_fused_swiglu_epilogue_changes_nothing(wide):
+    """SwiGLU in the gate|up GEMM epilogue (default) vs the separate interleaved-32 pass: the same bits reach the loss."""
+    dims, toks, masks, Lp, pts, start, sd, ref = wide
+    res = {}
+    for fuse in (True, False):
+        m = _model(dims, sd, False)
+        m.engine.use_fused_swiglu = fuse
+        loss = m.loss_and_backward(toks.cuda(), masks.cuda(), pts.cuda(), Lp, dims.tok.pad, fps_start=start)
+        res[fuse] = (float(loss), m.engine.main_grad["model.point_proj.4.weight"].clone(), m.engine.main_grad["lm_head.weight"].clone())
+        assert m.engine.gu_il
+        del m
+        torch.cuda.empty_cache()
+    assert abs(res[True][0] - res[False][0]) <= 1e-6 * abs(res[False][0])             # the scalar loss is an atomic fp32 sum
+    assert torch.equal(res[True][1], res[False][1]) and torch.equal(res[True][2], res[False][2])
+
+
 def test_bf16_7b_width_frozen_equals_unfrozen_on_shared_gradients(wide):
     """The stacked / K-concatenated weights of the frozen mode and the per-weight products of the unfrozen mode are two
     routes to the same dgrad: gradients of the tensors both modes train must agree to bf16 accumulation noise."""
