@@ -177,3 +177,55 @@ def test_depth_to_cloud_oracle_vs_golden_and_pillow(golden_dir):
         ref = np.array(Image.fromarray(pred).resize((W, H), Image.NEAREST))
         got = pred[OPC.nearest_table(h0, H)][:, OPC.nearest_table(w0, W)]
         assert np.array_equal(ref, got), (h0, w0, H, W)
+
+
+def test_trained_model_generation_parse_and_ade_chain(golden_dir):
+    """tiny_trained.npz (a tiny model trained with the reference's classes): the oracle's cached greedy decode reproduces the
+    reference's token ids, its string parser + rt2 scaler the trajectory the reference's `str_to_float` returned, its metrics the
+    reference's ADE / FDE — the CPU side of the end-to-end "ADE vs ref" chain (GPU side: tests/test_gpu_ade_e2e.py)."""
+    g = _load(golden_dir, "tiny_trained.npz")
+    dims = dims_tiny()
+    tok = dims.tok
+    sd = {k[2:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("w:")}
+    toks, masks = torch.from_numpy(g["tokens"]), torch.from_numpy(g["masks"])
+    Lp, n_new = int(g["prompt_len"]), int(g["n_new"])
+    pts = torch.stack([synth.synth_cloud(dims, i) for i in range(2)])
+    with torch.no_grad():
+        seq, _ = OPL.greedy_generate(sd, dims, toks[:, :Lp], masks[:, :Lp], pts, g["fps_start"], n_new)
+    assert np.array_equal(seq.numpy(), g["gen_sequences"])
+
+    def to_string(ids):
+        ids = ids.tolist()
+        if tok.eos in ids:
+            ids = ids[:ids.index(tok.eos)]
+        names = {tok.ts: "<ts>", tok.tsep: "<tsep>", tok.te: "<te>"}
+        return " ".join(f"<p{i - tok.p0}>" if tok.p0 <= i < tok.p0 + tok.num_bins else names.get(i, f"<unk{i}>") for i in ids)
+    for b in range(2):
+        s = to_string(seq[b, Lp:])
+        assert s == str(g[f"gen_string{b}"])
+        gen = OT.rt2_scaler(OT.parse_traj_string(s, tok.num_bins).copy(), [2.5, 0.1])
+        gt = OT.rt2_scaler(OT.parse_traj_string(to_string(toks[b, Lp:]), tok.num_bins).copy(), [2.5, 0.1])
+        assert np.array_equal(gen, g[f"gen_traj{b}"]) and np.array_equal(gt, g[f"gt_traj{b}"])
+        assert OT.ade(gen, gt) == float(g[f"ade{b}"]) and OT.fde(gen, gt) == float(g[f"fde{b}"])
+        assert OT.ade_as_called(gen, gt) == float(g[f"ade_as_called{b}"])
+    assert "<tsep> <p" in str(g["gen_string0"]) and float(g["ade0"]) > 0.1
+
+
+def test_bf16_autocast_golden_is_consistent_with_the_fp32_golden(golden_dir):
+    """tiny_model_bf16.npz records the reference under its training numerics (bf16 parameters + autocast) and its distance from the
+    fp32 run; the recorded distances must be what the two files imply (they are the bounds of the GPU bf16 tests)."""
+    g32, gb = _load(golden_dir, "tiny_model.npz"), _load(golden_dir, "tiny_model_bf16.npz")
+    for tag in ("frozen", "unfrozen"):
+        rel = abs(float(gb[f"{tag}:loss"]) - float(g32["loss"])) / abs(float(g32["loss"]))
+        assert rel == pytest.approx(float(gb[f"{tag}:loss_relerr_vs_fp32"]), rel=1e-9)
+        assert 1e-3 < rel < 2e-2
+        n = 0
+        for k in gb.files:
+            if k.startswith(f"{tag}:grad:"):
+                name = k[len(tag) + 6:]
+                a, b = gb[k].astype(np.float64), g32["grad:" + name].astype(np.float64)
+                r = float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+                assert r == pytest.approx(float(gb[f"{tag}:relerr_vs_fp32:{name}"]), rel=1e-6) and r < 5e-2
+                n += 1
+        assert n >= 7
+    assert str(gb["frozen:logits_dtype"]) == "torch.bfloat16"
