@@ -57,9 +57,12 @@ class GradSync:
     reduced on a side stream as soon as they close; `finish()` joins.  wire_dtype=torch.bfloat16: buckets of at least
     `wire_min_bytes` cross the fabric as bf16 with fp32 accumulation (see the module docstring)."""
 
-    def __init__(self, group=None, wire_dtype=None, wire_min_bytes=32 << 20, bucket_bytes=1 << 30):
+    def __init__(self, group=None, wire_dtype=None, wire_min_bytes=32 << 20, bucket_bytes=1 << 30, run_single=False):
+        """run_single=True: a one-rank group still goes through every collective (tests drive the real RCCL backend that way
+        on a one-GPU box; RCCL refuses two ranks on one device)."""
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.skip = self.world == 1 and not (run_single and dist.is_initialized())
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.stream = None
         self.wire_dtype, self.wire_min_bytes, self.bucket_bytes = wire_dtype, wire_min_bytes, bucket_bytes
@@ -77,7 +80,7 @@ class GradSync:
         self._bucket_id = 0
 
     def ready(self, name, buf: torch.Tensor):
-        if self.world == 1:
+        if self.skip:
             return
         self.open.append((name, buf))
         self.open_bytes += buf.numel() * buf.element_size()
@@ -85,13 +88,13 @@ class GradSync:
             self.flush()
 
     def ready_flat(self, tag, flat: torch.Tensor):
-        if self.world == 1:
+        if self.skip:
             return
         self.flush()
         self._reduce(flat.view(-1), None)
 
     def flush(self):
-        if self.world == 1 or not self.open:
+        if self.skip or not self.open:
             return
         bufs = [b for _, b in self.open]
         self.open, self.open_bytes = [], 0
