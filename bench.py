@@ -192,6 +192,8 @@ def main():
     ap.add_argument("--workload", default="train", choices=["train", "decode"],
                     help="train: BASELINE.json configs[1], the headline (default).  decode: configs[4], bs=256 greedy decode of 32 steps in one hipGraph "
                          "(tokens/s + HBM roofline; 1 GPU)")
+    ap.add_argument("--force-dist", action="store_true", help="N=1 only: create a one-rank RCCL group and run the gradient exchange through it anyway "
+                                                              "(every collective of the N>1 step on the real backend; the line is marked rehearsal)")
     ap.add_argument("--dry-launch", action="store_true", help="launcher self-test: ranks rendezvous (gloo, host tensors), check the world size and exit without touching the GPU")
     a = ap.parse_args()
 
@@ -236,6 +238,11 @@ def main():
             dist.init_process_group("gloo")
         if dist.get_world_size() != a.gpus:
             raise SystemExit(f"process group has {dist.get_world_size()} ranks, --gpus {a.gpus}")
+    elif a.force_dist:
+        import socket
+        sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
 
     from egoscaler_amd import ops, synth
     from egoscaler_amd.config import dims_7b
@@ -272,7 +279,7 @@ def main():
     model.engine.prepared = False
     model.train()
     opt = EgoAdamW(model, lr=2e-5)
-    sync = GradSync(wire_dtype=torch.bfloat16) if world > 1 else None      # large fp32 gradient buffers cross xGMI as bf16
+    sync = GradSync(wire_dtype=torch.bfloat16, run_single=a.force_dist) if (world > 1 or a.force_dist) else None      # large fp32 gradient buffers cross xGMI as bf16
     model.engine.grad_sync = sync
 
     # ---- synthetic batch, resident in HBM before the timed region (rank r gets samples r*B .. r*B+B-1)
@@ -368,7 +375,7 @@ def main():
                    "grad_sync": (dict(sync.stats) if sync is not None else None),
                    "algorithmic_tflop_per_clip": round(fl["fwd_bwd"] / 1e12, 3),
                    "model_tflops_per_gpu": round(fl["fwd_bwd"] * value / 1e12, 2), "loss": round(float(loss), 4),
-                   "valid": a.layers is None and B == 8},
+                   "valid": a.layers is None and B == 8, "rehearsal_one_rank_rccl_group": bool(a.force_dist)},
     }
     if roof is not None:
         out["roofline"] = roof
@@ -380,7 +387,7 @@ def main():
             except Exception as e:      # the oracle is a reported baseline; never fail the bench on it
                 out["cpu_baseline"] = {"value": None, "unit": "clips/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or a.force_dist:
         dist.destroy_process_group()
 
 
