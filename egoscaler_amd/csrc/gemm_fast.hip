@@ -408,34 +408,29 @@ void gemm_nt_bf16_8phase_kernel(FastArgs g) {
     if (ksl > 1 && g.tickets) {
         // ---- K-sliced tail tile, combined in the launch (the protocol of the persistent kernel below; cdna_hip_programming.md §5
         // "Projection GEMM at M = 256" item 2): every slice block drops its partial tile as a register-major fp32 slab (1-KiB wave
-        // stores), publishes it (agent-scope release) and draws a ticket; the block that draws the LAST ticket acquires, sums the
-        // slabs in slice order and runs the epilogue.  Nobody waits for anybody.
+        // stores) and draws a ticket; the block that draws the LAST ticket sums the slabs in slice order and runs the epilogue.  Nobody waits for anybody.
+        // Slab data moves with sc1 buffer stores / loads (write-through past the XCD's L2, reads that bypass it): no agent-scope
+        // release (= whole-L2 write-back) or acquire (= invalidate) in the middle of the launch; the ticket is a relaxed atomic
+        // issued after the block's stores have completed (vmcnt(0) + barrier).
         const int tile = (blockIdx.x - g.full_tiles) / ksl;
-        f32x4* slab = reinterpret_cast<f32x4*>(g.ws) + (long long)tile * ksl * 16384;
-        f32x4* my = slab + ((long long)kz * 8 + wave) * 2048;
+        char* slab = reinterpret_cast<char*>(g.ws) + (long long)tile * ksl * 262144;
+        {
+            __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(slab + ((long long)kz * 8 + wave) * 32768, 0, 32768, 0x00020000);
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int i = 0; i < 8; ++i) my[(j * 8 + i) * 64 + lane] = acc[j][i];
+                for (int i = 0; i < 8; ++i)
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[j][i]), r, ((j * 8 + i) * 64 + lane) * 16, 0, 16);
+        }
         int* flag = reinterpret_cast<int*>(smem);                       // the operand stages are idle: every DMA has drained (above)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        if (threadIdx.x == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            *flag = __hip_atomic_fetch_add(g.tickets + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+        if (threadIdx.x == 0) *flag = __hip_atomic_fetch_add(g.tickets + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         const int tk = *const_cast<volatile int*>(flag);
         if (tk != ksl - 1) return;                                      // block-uniform: somebody else finishes this tile
-        if (threadIdx.x == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            __hip_atomic_store(g.tickets + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // leave the word as we found it
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
+        if (threadIdx.x == 0) __hip_atomic_store(g.tickets + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // leave the word as we found it
         // two slices: mine + the other (commutative).  More: every slab in slice order, mine read back, so that the sum does not
         // depend on the arrival order
         const bool all = ksl > 2;
@@ -447,11 +442,12 @@ void gemm_nt_bf16_8phase_kernel(FastArgs g) {
         }
         for (int z = 0; z < ksl; ++z) {
             if (z == kz && !all) continue;
-            const f32x4* os = slab + ((long long)z * 8 + wave) * 2048;
+            __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(slab + ((long long)z * 8 + wave) * 32768, 0, 32768, 0x00020000);
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int i = 0; i < 8; ++i) acc[j][i] += os[(j * 8 + i) * 64 + lane];
+                for (int i = 0; i < 8; ++i)
+                    acc[j][i] += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, ((j * 8 + i) * 64 + lane) * 16, 0, 16));
         }
         gemm_epilogue<TC, 8>(g, acc, mb, nb, lane);
         return;
@@ -716,16 +712,19 @@ void gemm_nt_bf16_p8_kernel(FastArgs g, P8Sched sc) {
             const int t0 = it.rt * sc.pp;
             const int b_first = p8_owner(sc, t0), b_last = p8_owner(sc, t0 + sc.pp - 1);
             const int which = (it.rt == lo / sc.pp) ? 0 : 1;
-            f32x4* my = reinterpret_cast<f32x4*>(sc.slabs) + ((long long)(v * 2 + which) * 8 + wave) * 2048;
+            {   // sc1 stores (write-through past this XCD's L2) + vmcnt(0): the slab is visible device-wide before the ticket is
+                // drawn, without an agent-scope release (a write-back of the whole L2 in mid-launch)
+                __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(sc.slabs) + ((long long)(v * 2 + which) * 8 + wave) * 32768,
+                                                                             0, 32768, 0x00020000);
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+                for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int i = 0; i < 8; ++i) my[(j * 8 + i) * 64 + lane] = acc[j][i];
+                    for (int i = 0; i < 8; ++i)
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[j][i]), r, ((j * 8 + i) * 64 + lane) * 16, 0, 16);
+            }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             if (threadIdx.x == 0) {
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 const int tk = __hip_atomic_fetch_add(sc.tickets + it.rt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 *flag = tk;
             }
@@ -736,13 +735,9 @@ void gemm_nt_bf16_p8_kernel(FastArgs g, P8Sched sc) {
             __builtin_amdgcn_s_barrier();                              // everybody has read the flag before it can be rewritten
             do_epilogue = (tk == b_last - b_first);
             if (do_epilogue) {                                         // block-uniform
-                if (threadIdx.x == 0) {
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                    __hip_atomic_store(sc.tickets + it.rt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // leave the counter as we found it
-                }
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-                asm volatile("" ::: "memory");
+                if (threadIdx.x == 0) __hip_atomic_store(sc.tickets + it.rt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // leave the counter as we found it
+                // the other slabs are read with sc1 loads (never served from this XCD's L2): no acquire / L2 invalidate, which would
+                // also evict the operand panels the neighbouring CUs are streaming
                 // two sharers: mine + theirs (commutative, so the arrival order cannot show).  More: sum EVERY slab in block order,
                 // my own included (read back from the workspace), so the result does not depend on who arrived last
                 const bool all = (b_last - b_first) >= 2;
@@ -757,11 +752,13 @@ void gemm_nt_bf16_p8_kernel(FastArgs g, P8Sched sc) {
                     int olo, ohi;
                     p8_range(sc, ob, olo, ohi);
                     const int ow = (it.rt == olo / sc.pp) ? 0 : 1;
-                    const f32x4* os = reinterpret_cast<const f32x4*>(sc.slabs) + ((long long)(ob * 2 + ow) * 8 + wave) * 2048;
+                    __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(sc.slabs) + ((long long)(ob * 2 + ow) * 8 + wave) * 32768,
+                                                                                 0, 32768, 0x00020000);
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
 #pragma unroll
-                        for (int i = 0; i < 8; ++i) acc[j][i] += os[(j * 8 + i) * 64 + lane];
+                        for (int i = 0; i < 8; ++i)
+                            acc[j][i] += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, ((j * 8 + i) * 64 + lane) * 16, 0, 16));
                 }
             }
         }
@@ -1092,10 +1089,12 @@ int egomi_gemm_fast_try(const egomi_gemm_desc* d0, hipStream_t s) {
         if (dl.workspace_bytes > 4096) { tickets = (int*)dl.workspace; dl.workspace = (char*)dl.workspace + 4096; dl.workspace_bytes -= 4096; }   // scratch starts behind them
         else { dl.workspace = nullptr; dl.workspace_bytes = 0; }
     }
-    // In-launch combine of the K-sliced tail tiles (last-arriver tickets) is built and tested but NOT the default: measured in
-    // the training step on one box, A/B in alternation, 139.1 ms/step vs 136.6 with the separate combine launch (kernel + combine
-    // 427 us vs 418 us per product).  The last arriver sums S x 256 KB of slabs alone, on the critical path at the very end of
-    // the launch, where the separate splitk_reduce_kernel spreads the same bytes over every CU.  EGOMI_GEMM_FOLD=1 selects it.
+    // In-launch combine of the K-sliced tail tiles (last-arriver tickets) is built and tested but NOT the default.  Measured in the
+    // training step on one box, arms alternated: with agent-scope release/acquire fences around the slabs 139.1 ms/step vs 136.6
+    // with the separate combine launch; with sc1 slab stores/loads and no fence (the present form) 136.4 vs 136.15 — the fences
+    // (whole-L2 write-back / invalidate in mid-launch) were the 2.3 ms, what remains is the last arriver summing S x 256 KB
+    // alone at the very end of the launch, where splitk_reduce_kernel spreads the same bytes over every CU.  EGOMI_GEMM_FOLD=1
+    // selects it.
     static int fold = -1;
     if (fold < 0) { const char* e = getenv("EGOMI_GEMM_FOLD"); fold = e ? atoi(e) : 0; }
     if (!fold && dl.ws_tickets_zeroed != 2) tickets = nullptr;
