@@ -178,8 +178,18 @@ __device__ __forceinline__ void store_rows_via_lds(char* wbuf, const f32x16 (&ac
     }
 }
 
+// Block order of the three kernels (1-D grid of nblk x H x B): rank-major — every (b, h) pair's LONGEST causal block first,
+// then every pair's second longest, ... (longest-processing-time dispatch: the blocks still running at the end of the launch
+// are the shortest ones).  H*B % 8 == 0 keeps a pair on one XCD for all its blocks (block index mod 8 picks the XCD), so the
+// K/V rows (resp. Q/dO rows) its blocks share are fetched into one L2, not eight.
+__device__ __forceinline__ void attn_block_map(const AttnArgs& a, int& rank, int& h, int& b) {
+    const int pairs = a.H * a.B;
+    rank = blockIdx.x / pairs;
+    const int pair = blockIdx.x - rank * pairs;
+    b = pair / a.H; h = pair - b * a.H;
+}
 // =================================================================================================
-// forward: grid (ceil(S/128), H, B), 4 waves x 32 queries, KV tiles of 64 keys, K/V double-buffered
+// forward: grid ceil(S/128) * H * B (attn_block_map), 4 waves x 32 queries, KV tiles of 64 keys, K/V double-buffered
 // in LDS by LDS-DMA (one tile in flight across the barrier: counted vmcnt + raw s_barrier)
 // =================================================================================================
 #define AT_MAXS 4096
@@ -190,7 +200,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
     char* sMask = smem + 2 * 2 * TB;
     const int lane = threadIdx.x & 63, half = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int b = blockIdx.z, h = blockIdx.y, q0 = (gridDim.x - 1 - blockIdx.x) * 128;   // causal: longest blocks first
+    int rank, h, b;
+    attn_block_map(a, rank, h, b);
+    const int q0 = ((a.S + 127) / 128 - 1 - rank) * 128;             // causal: longest blocks first
+    const bool wave_dead = q0 + wave * 32 >= a.S;                     // ragged last block: no query in this wave (it still moves its DMA share)
     const long long row_base = (long long)b * a.S;
     const bf16_t* Q = a.q + row_base * a.ld_qkv + h * HD;
     const bf16_t* K = a.k + row_base * a.ld_qkv + h * HD;
@@ -237,6 +250,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
         __builtin_amdgcn_s_barrier();
         const unsigned long long kmask = __ballot(sMask[kv0 + lane] != 0);
 
+        if (!wave_dead) {
         float s[2][16];
         float mloc = -INFINITY;
         // causal: a 32-key sub-tile that starts beyond the wave's last query is masked for every lane -> no MFMAs
@@ -305,6 +319,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
                     o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_tr8_t<HD>(sV, 32 * sub + 16 * st, 32 * dt, lane), pb, o[dt], 0, 0, 0);
             }
         }
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                                  // buffer (t&1) is free for the DMA of tile t+2
     }
@@ -367,7 +382,10 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_dq_kernel(AttnArgs a) {
     char* sMask = smem + NST * 2 * 64 * 256;
     const int lane = threadIdx.x & 63, half = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int b = blockIdx.z, h = blockIdx.y, q0 = (gridDim.x - 1 - blockIdx.x) * 128;   // causal: longest blocks are dispatched first
+    int rank, h, b;
+    attn_block_map(a, rank, h, b);
+    const int q0 = ((a.S + 127) / 128 - 1 - rank) * 128;             // causal: longest blocks are dispatched first
+    const bool wave_dead = q0 + wave * 32 >= a.S;                     // ragged last block: no query in this wave
     const long long row_base = (long long)b * a.S;
     const bf16_t* Q = a.q + row_base * a.ld_qkv + h * AT_HD;
     const bf16_t* K = a.k + row_base * a.ld_qkv + h * AT_HD;
@@ -426,7 +444,7 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_dq_kernel(AttnArgs a) {
         const unsigned long long kmask = __ballot(sMask[kv0 + lane] != 0);
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
-            if (a.causal && (kv0 + 32 * sub > q0 + wave * 32 + 31)) continue;       // wave-uniform: every P of this sub-tile is 0
+            if (wave_dead || (a.causal && (kv0 + 32 * sub > q0 + wave * 32 + 31))) continue;       // wave-uniform: every P of this sub-tile is 0
             f32x16 x, dp;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { x[r] = 0.f; dp[r] = 0.f; }
@@ -479,7 +497,9 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_dkdv_kernel(AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, half = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int b = blockIdx.z, h = blockIdx.y, kb0 = blockIdx.x * 128;                   // causal: key block 0 sweeps the most queries and is dispatched first
+    int rank, h, b;
+    attn_block_map(a, rank, h, b);
+    const int kb0 = rank * 128;                                       // causal: key block 0 sweeps the most queries and is dispatched first
     const long long row_base = (long long)b * a.S;
     const bf16_t* Q = a.q + row_base * a.ld_qkv + h * AT_HD;
     const bf16_t* K = a.k + row_base * a.ld_qkv + h * AT_HD;
@@ -632,7 +652,7 @@ extern "C" int egomi_attn_fwd(const egomi_attn_desc* d, egomi_stream_t stream) {
     if (!d->o || d->ld_o % 8 || d->ld_o < d->head_dim * d->H || ((uintptr_t)d->o & 15)) return EGOMI_E_SHAPE;
     if (d->S > AT_MAXS) return EGOMI_E_UNSUPPORTED;
     AttnArgs a = attn_args(d);
-    const dim3 grid((d->S + 127) / 128, d->H, d->B);
+    const dim3 grid((unsigned)(((d->S + 127) / 128) * d->H * d->B));
     const size_t lds = 2 * 2 * 64 * 2 * (size_t)d->head_dim + (size_t)((d->S + 63) / 64) * 64;
     if (d->head_dim == 128) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -658,7 +678,7 @@ extern "C" int egomi_attn_bwd(const egomi_attn_desc* d, egomi_stream_t stream) {
     EGOMI_LAUNCH(attn_delta_kernel, dim3((unsigned)((items + 15) / 16)), dim3(256), 0, s, a.dout, (const bf16_t*)d->o, d->delta, d->B, d->H, d->S, d->ld_o);
     const size_t lds_q = ((occ_dq2() ? 2 : 3) * 2 * 64 * 256) + (size_t)((d->S + 63) / 64) * 64;
     const int occ = attn_occ();
-    const dim3 grid((d->S + 127) / 128, d->H, d->B);
+    const dim3 grid((unsigned)(((d->S + 127) / 128) * d->H * d->B));
     if (occ & 1) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q);
         EGOMI_LAUNCH(attn_bwd_dq_kernel<2>, grid, dim3(256), lds_q, s, a);
