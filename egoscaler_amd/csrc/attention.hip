@@ -25,7 +25,7 @@ typedef __attribute__((address_space(3))) bf16x4_t lds_bf16x4;
 
 struct AttnArgs {
     const bf16_t* q; const bf16_t* k; const bf16_t* v; bf16_t* o; float* lse;
-    const bf16_t* dout; const float* delta; bf16_t* dq; bf16_t* dk; bf16_t* dv;
+    const bf16_t* dout; float* delta; bf16_t* dq; bf16_t* dk; bf16_t* dv;
     const uint8_t* key_mask;
     int B, H, S;
     long long ld_qkv, ld_o, ld_dqkv;
@@ -178,15 +178,58 @@ __device__ __forceinline__ void store_rows_via_lds(char* wbuf, const f32x16 (&ac
     }
 }
 
+#ifdef ATTN_STAMP
+// Timing stamps (debug builds only, -DATTN_STAMP; tools/debug/attn_stamp.py): wave 0 of every block accumulates s_memtime
+// deltas per segment of the forward loop and adds them to g_attn_stamp[] at the end.
+__device__ unsigned long long g_attn_stamp[16];
+extern "C" int egomi_attn_stamp_read(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_attn_stamp), sizeof(g_attn_stamp)); }
+extern "C" int egomi_attn_stamp_reset() { unsigned long long z[16] = {0}; return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_attn_stamp), z, sizeof(z)); }
+#define STAMP_DECL unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long st_prev = 0, st_t0 = 0; (void)st_t0;
+#define STAMP_NOW(var) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory"); __builtin_amdgcn_sched_barrier(0); }
+#define STAMP_START { STAMP_NOW(st_prev) st_t0 = st_prev; }
+#define STAMP(i) { unsigned long long st_n; STAMP_NOW(st_n) st_acc[i] += st_n - st_prev; st_prev = st_n; }
+#define STAMP_FLUSH if (threadIdx.x == 0) { for (int i = 0; i < 8; ++i) atomicAdd(&g_attn_stamp[i], st_acc[i]); atomicAdd(&g_attn_stamp[8], 1ull); }
+#else
+#define STAMP_DECL
+#define STAMP_START
+#define STAMP(i)
+#define STAMP_FLUSH
+#endif
+
 // Block order of the three kernels (1-D grid of nblk x H x B): rank-major — every (b, h) pair's LONGEST causal block first,
 // then every pair's second longest, ... (longest-processing-time dispatch: the blocks still running at the end of the launch
 // are the shortest ones).  H*B % 8 == 0 keeps a pair on one XCD for all its blocks (block index mod 8 picks the XCD), so the
-// K/V rows (resp. Q/dO rows) its blocks share are fetched into one L2, not eight.
+// K/V rows (resp. Q/dO rows) its blocks share are fetched into one L2, not eight.  (Pair-major order inside each XCD — a pair's
+// blocks back to back, for L2 hits on its K/V tiles — measured slower: fwd 86 vs 79 us, bwd 236 vs 220: the tail decides.)
 __device__ __forceinline__ void attn_block_map(const AttnArgs& a, int& rank, int& h, int& b) {
     const int pairs = a.H * a.B;
     rank = blockIdx.x / pairs;
     const int pair = blockIdx.x - rank * pairs;
     b = pair / a.H; h = pair - b * a.H;
+}
+// Key-padding mask -> LDS bytes (1 = visible).  The global loads are unconditional (index clamped) and issued together by
+// mask_fetch(); mask_commit() writes them to LDS later, after the block's other loads have been issued — a load under a
+// per-element condition makes hipcc branch and wait vmcnt(0) per element (cdna_hip_programming.md §5, ".s-level traps" (c)).
+#define AT_MASK_IT 4                                                   // x 256 threads = 1024 keys in registers; longer rows loop
+__device__ __forceinline__ void mask_fetch(const AttnArgs& a, long long row_base, int nkeys, uint8_t (&mv)[AT_MASK_IT]) {
+#pragma unroll
+    for (int i = 0; i < AT_MASK_IT; ++i) {
+        int j = threadIdx.x + 256 * i;
+        j = j < a.S ? j : a.S - 1;
+        mv[i] = (a.key_mask && 256 * i < nkeys) ? a.key_mask[row_base + j] : (uint8_t)1;      // block-uniform conditions
+    }
+}
+__device__ __forceinline__ void mask_commit(const AttnArgs& a, long long row_base, int nkeys, const uint8_t (&mv)[AT_MASK_IT], char* sMask) {
+#pragma unroll
+    for (int i = 0; i < AT_MASK_IT; ++i) {
+        const int j = threadIdx.x + 256 * i;
+        if (j < nkeys) sMask[j] = j < a.S && mv[i] != 0;
+    }
+    for (int j = threadIdx.x + 256 * AT_MASK_IT; j < nkeys; j += 256) {
+        uint8_t ok = j < a.S;
+        if (ok && a.key_mask) ok = a.key_mask[row_base + j] != 0;
+        sMask[j] = ok;
+    }
 }
 // =================================================================================================
 // forward: grid ceil(S/128) * H * B (attn_block_map), 4 waves x 32 queries, KV tiles of 64 keys, K/V double-buffered
@@ -213,15 +256,21 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
 
     int last = q0 + 127 < a.S - 1 ? q0 + 127 : a.S - 1;
     const int ntiles = a.causal ? (last / 64 + 1) : ((a.S + 63) / 64);
-    // key-padding mask -> LDS bytes (1 = visible), once
-    for (int j = threadIdx.x; j < ntiles * 64; j += 256) {
-        uint8_t ok = j < a.S;
-        if (ok && a.key_mask) ok = a.key_mask[row_base + j] != 0;
-        sMask[j] = ok;
-    }
+    STAMP_DECL
+    STAMP_START
+    tile_dma_t<64, HD>(K, a.ld_qkv, 0, a.S - 1, smem, wave, lane);
+    tile_dma_t<64, HD>(V, a.ld_qkv, 0, a.S - 1, smem + TB, wave, lane);
     bf16x8 qf[HD / 16];
 #pragma unroll
     for (int ks = 0; ks < HD / 16; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(Q + (long long)qr * a.ld_qkv + 16 * ks + 8 * half);
+    uint8_t mv[AT_MASK_IT];
+    mask_fetch(a, row_base, ntiles * 64, mv);
+    // The Q fragments are ordinary loads: consume them HERE (an empty asm that names them), so that the compiler's wait for
+    // them — vmcnt(0), it does not count across LDS-DMAs — lands before the loop instead of in front of every tile's first MFMA,
+    // where it drained the K/V prefetch of the next tile (cdna_hip_programming.md §5 "three .s-level traps", (b))
+#pragma unroll
+    for (int ks = 0; ks < HD / 16; ++ks) asm volatile("" :: "v"(qf[ks]));
+    mask_commit(a, row_base, ntiles * 64, mv, sMask);                  // visible to the block after the loop's first barrier
 
     f32x16 o[HD / 32];
 #pragma unroll
@@ -231,8 +280,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
     float m_run = -INFINITY, l_run = 0.f;
     const float sc2 = a.scale * 1.4426950408889634f;
 
-    tile_dma_t<64, HD>(K, a.ld_qkv, 0, a.S - 1, smem, wave, lane);
-    tile_dma_t<64, HD>(V, a.ld_qkv, 0, a.S - 1, smem + TB, wave, lane);
+    STAMP(0)                                                           // prologue
     for (int t = 0; t < ntiles; ++t) {
         const int kv0 = t * 64;
         char* sK = smem + (t & 1) * (2 * TB);
@@ -246,8 +294,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
+        STAMP(1)                                                       // DMA issue + wait for tile t
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+        STAMP(2)                                                       // barrier A
         const unsigned long long kmask = __ballot(sMask[kv0 + lane] != 0);
 
         if (!wave_dead) {
@@ -286,6 +336,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
                 }
             }
         }
+        STAMP(3)                                                       // QK + masks
         mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64)) * sc2;            // sc2 > 0: max commutes with the scale
         const float m_new = fmaxf(m_run, mloc);
         const float m_safe = m_new == -INFINITY ? 0.f : m_new;
@@ -308,6 +359,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
         }
+        STAMP(4)                                                       // softmax
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
             if (a.causal && (kv0 + 32 * sub > wave_qmax)) continue;                  // P is all zero there
@@ -319,9 +371,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
                     o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_tr8_t<HD>(sV, 32 * sub + 16 * st, 32 * dt, lane), pb, o[dt], 0, 0, 0);
             }
         }
+        STAMP(5)                                                       // PV issue
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                                  // buffer (t&1) is free for the DMA of tile t+2
+        STAMP(6)                                                       // barrier B
     }
     if (HD == 128) {
         if constexpr (HD == 128) {
@@ -331,6 +385,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
         }
         if (qi < a.S && half == 0 && a.lse)
             a.lse[((long long)b * a.H + h) * a.S + qi] = (m_run == -INFINITY) ? INFINITY : m_run * 0.6931471805599453f + logf(l_run);
+        STAMP(7)                                                       // epilogue
+        STAMP_FLUSH
     } else if (qi < a.S) {
         const float inv = l_run > 0.f ? 1.0f / l_run : 0.f;
         bf16_t* orow = a.o + (row_base + qi) * a.ld_o + h * HD;
@@ -350,29 +406,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
 
 
 // =================================================================================================
-// backward 1/3: delta[b,h,q] = sum_d dO[q,d] * O[q,d]   (one wave per (row, head))
-// =================================================================================================
-__global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* dout, const bf16_t* o, float* delta, int B, int H, int S, long long ld_o) {
-    // 16 lanes x 8 elements (one 16-B load each of dO and O) per (row, head)
-    const long long item = (long long)blockIdx.x * 16 + (threadIdx.x >> 4);
-    const int l16 = threadIdx.x & 15;
-    const bool live = item < (long long)B * S * H;
-    const long long it = live ? item : 0;
-    const int h = (int)(it % H);
-    const long long row = it / H;
-    const long long off = row * ld_o + h * AT_HD + l16 * 8;
-    float x[8], y[8];
-    load8<bf16_t>(dout + off, x);
-    load8<bf16_t>(o + off, y);
-    float v = 0.f;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) v = fmaf(x[j], y[j], v);
-    v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
-    if (live && l16 == 0) delta[((row / S) * H + h) * S + (row % S)] = v;
-}
-
-// =================================================================================================
-// backward 2/3: dQ.  Same structure as the forward (query on the lane): per 32-key sub-tile
+// backward 1/2: dQ (and delta).  Same structure as the forward (query on the lane): per 32-key sub-tile
 //   X = K.Q^T, dP^T = V.dO^T, dS^T = P^T*(dP^T - delta), dQ^T += K^T.dS^T
 // =================================================================================================
 template <int OCC>
@@ -395,27 +429,6 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_dq_kernel(AttnArgs a) {
     const int qr = qi < a.S ? qi : a.S - 1;
     int last = q0 + 127 < a.S - 1 ? q0 + 127 : a.S - 1;
     const int ntiles = a.causal ? (last / 64 + 1) : ((a.S + 63) / 64);
-    for (int j = threadIdx.x; j < ntiles * 64; j += 256) {
-        uint8_t ok = j < a.S;
-        if (ok && a.key_mask) ok = a.key_mask[row_base + j] != 0;
-        sMask[j] = ok;
-    }
-    bf16x8 qf[8], dof[8];
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks) {
-        qf[ks] = *reinterpret_cast<const bf16x8*>(Q + (long long)qr * a.ld_qkv + 16 * ks + 8 * half);
-        dof[ks] = *reinterpret_cast<const bf16x8*>(DO + (long long)qr * a.ld_o + 16 * ks + 8 * half);
-    }
-    const long long st = ((long long)b * a.H + h) * a.S + qr;
-    const float lse2 = a.lse[st] * 1.4426950408889634f;
-    const float dlt = a.delta[st];
-    const float sc2 = a.scale * 1.4426950408889634f;
-    f32x16 dq[4];
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) dq[dt][r] = 0.f;
-
     // NST-1 tiles in flight before the loop; past the last tile the DMA re-loads it into a stage nobody reads any more,
     // which keeps the vmcnt arithmetic constant (8 DMAs per tile and wave)
 #pragma unroll
@@ -424,6 +437,42 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_dq_kernel(AttnArgs a) {
         tile_dma<64>(K, a.ld_qkv, ti * 64, a.S - 1, smem + i * (2 * 64 * 256), wave, lane);
         tile_dma<64>(V, a.ld_qkv, ti * 64, a.S - 1, smem + i * (2 * 64 * 256) + 64 * 256, wave, lane);
     }
+    uint8_t mv[AT_MASK_IT];
+    mask_fetch(a, row_base, ntiles * 64, mv);
+    bf16x8 qf[8], dof[8];
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+        qf[ks] = *reinterpret_cast<const bf16x8*>(Q + (long long)qr * a.ld_qkv + 16 * ks + 8 * half);
+        dof[ks] = *reinterpret_cast<const bf16x8*>(DO + (long long)qr * a.ld_o + 16 * ks + 8 * half);
+    }
+    const long long st = ((long long)b * a.H + h) * a.S + qr;
+    const float lse2 = a.lse[st] * 1.4426950408889634f;
+    // delta[b,h,q] = sum_d dO[q,d] * O[q,d]: this lane holds 64 of its query's 128 dO values, the other half-wave the rest.
+    // Written out for the dK/dV kernel, which runs after this one on the same stream.
+    float dlt = 0.f;
+    {
+        const bf16_t* Orow = a.o + (row_base + qr) * a.ld_o + h * AT_HD;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            const bf16x8 of = *reinterpret_cast<const bf16x8*>(Orow + 16 * ks + 8 * half);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) dlt = fmaf((float)dof[ks][e], (float)of[e], dlt);
+        }
+        dlt += __shfl_xor(dlt, 32, 64);
+        if (half == 0 && qi < a.S) a.delta[st] = dlt;
+    }
+    const float sc2 = a.scale * 1.4426950408889634f;
+    // ordinary loads are consumed before the first LDS-DMA is outstanding (see attn_fwd_kernel)
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) asm volatile("" :: "v"(qf[ks]), "v"(dof[ks]));
+    asm volatile("" :: "v"(lse2), "v"(dlt));
+    mask_commit(a, row_base, ntiles * 64, mv, sMask);                  // visible to the block after the loop's first barrier
+    f32x16 dq[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dq[dt][r] = 0.f;
+
     int stg = 0;
     for (int t = 0; t < ntiles; ++t) {
         const int kv0 = t * 64;
@@ -486,7 +535,7 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_dq_kernel(AttnArgs a) {
 }
 
 // =================================================================================================
-// backward 3/3: dK, dV.  Key on the lane: a workgroup owns 128 keys (4 waves x 32), keeps their K and
+// backward 2/2: dK, dV.  Key on the lane: a workgroup owns 128 keys (4 waves x 32), keeps their K and
 // V fragments and the dK^T / dV^T accumulators in registers (one wave per SIMD, 512-register file) and
 // sweeps the queries in tiles of 32 (Q, dO, LSE, delta tiles double-buffered in LDS by LDS-DMA):
 //   X = Q.K^T, dP = dO.V^T, P = exp2(sc2*X - lse2), dS = P*(dP - delta), dV^T += dO^T.P, dK^T += Q^T.dS
@@ -522,6 +571,13 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_dkdv_kernel(AttnArgs a) {
     for (int ks = 0; ks < 8; ++ks) {
         kf[ks] = *reinterpret_cast<const bf16x8*>(K + (long long)kr * a.ld_qkv + 16 * ks + 8 * half);
         if (OCC != 2) vf[ks] = *reinterpret_cast<const bf16x8*>(V + (long long)kr * a.ld_qkv + 16 * ks + 8 * half);
+    }
+    // ordinary loads are consumed before the query-tile DMAs start (see attn_fwd_kernel)
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) asm volatile("" :: "v"(kf[ks]));
+    if (OCC != 2) {
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) asm volatile("" :: "v"(vf[ks]));
     }
     f32x16 dk[4], dv[4];
 #pragma unroll
@@ -674,8 +730,6 @@ extern "C" int egomi_attn_bwd(const egomi_attn_desc* d, egomi_stream_t stream) {
     if (d->rope_cos && (((uintptr_t)d->rope_cos | (uintptr_t)d->rope_sin) & 15)) return EGOMI_E_SHAPE;
     AttnArgs a = attn_args(d);
     hipStream_t s = (hipStream_t)stream;
-    const long long items = (long long)d->B * d->S * d->H;
-    EGOMI_LAUNCH(attn_delta_kernel, dim3((unsigned)((items + 15) / 16)), dim3(256), 0, s, a.dout, (const bf16_t*)d->o, d->delta, d->B, d->H, d->S, d->ld_o);
     const size_t lds_q = ((occ_dq2() ? 2 : 3) * 2 * 64 * 256) + (size_t)((d->S + 63) / 64) * 64;
     const int occ = attn_occ();
     const dim3 grid((unsigned)(((d->S + 127) / 128) * d->H * d->B));

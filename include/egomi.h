@@ -161,7 +161,7 @@ int egomi_gemm_kernel_id(const egomi_gemm_desc* desc);
  * three column slices of one [B*S, 3*H*hd] buffer).  o: [B*S, H*hd] row stride ld_o.
  * mask: key j visible to query i iff (!causal || j <= i) && (key_mask == NULL || key_mask[b*S+j]).
  * lse [B,H,S] fp32 = log sum exp of the scaled, masked scores (saved for backward).
- * backward: delta [B,H,S] fp32 = rowsum(dout * o) (egomi_attn_bwd computes it into `delta`), then
+ * backward: delta [B,H,S] fp32 = rowsum(dout * o) (egomi_attn_bwd's dQ kernel computes it into `delta`, its dK/dV kernel reads it), then
  * dq/dk/dv written with row stride ld_dqkv (deterministic: no atomics).
  */
 typedef struct egomi_attn_desc {
