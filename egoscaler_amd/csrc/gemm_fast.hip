@@ -173,14 +173,21 @@ __device__ __forceinline__ void gemm_epilogue(const FastArgs& g, const f32x4 (&a
     }
 }
 
-template <typename TC, int BM, int BN>
-__global__ __launch_bounds__((BM / 64) * (BN / 64) * 64, (BM * BN == 256 * 128) ? 4 : 3)
+// NS = LDS stages.  1: load, barrier, multiply, barrier.  2: the DMA of K-step t+1 is issued before the MFMAs of step t and one
+// barrier per step remains (the guide's "glds, 2 LDS buffers, BK=64, vmcnt(0) + plain __syncthreads()" row) — the default of
+// the 128x128 tile: M = 256 decode projections 27 -> 22 us (N = K = 4096), 46 -> 41 (N = 11008), 41 -> 37 (K = 11008), lm_head
+// 98 -> 91; decode step 20.0 -> 19.5 ms.  A 4-stage ring (three K-steps in flight, counted vmcnt, raw barrier, one block per
+// CU) was measured SLOWER than two blocks per CU with two stages each (25 / 63 / 52 / 118 us, step 20.9 ms): at M = 256 the
+// second resident block is worth more than deeper prefetch.
+template <typename TC, int BM, int BN, int NS>
+__global__ __launch_bounds__((BM / 64) * (BN / 64) * 64, NS == 2 ? 2 : ((BM * BN == 256 * 128) ? 4 : 3))
 void gemm_nt_bf16_kernel(FastArgs g) {
     constexpr int MT = 4;                                                // 16-row MFMA tiles per wave in M (64 x 64 per wave)
     constexpr int WN = BN / 64, NW = (BM / 64) * WN;
     constexpr int A_PW = BM / 8 / NW, B_PW = BN / 8 / NW;               // 1-KiB DMA pieces (8 rows x 128 B) per wave
     constexpr int STAGE = (BM + BN) * FT_BK;
-    __shared__ __attribute__((aligned(16))) bf16_t smem[STAGE];
+    constexpr bool PF = NS == 2;
+    __shared__ __attribute__((aligned(16))) bf16_t smem[NS * STAGE];
     bf16_t* sA = smem;
     bf16_t* sB = smem + BM * FT_BK;
     const int lane = threadIdx.x & 63;
@@ -241,11 +248,27 @@ void gemm_nt_bf16_kernel(FastArgs g) {
         t_begin = blockIdx.y * per;
         nt = t_begin + per < nt ? t_begin + per : nt;
     }
+    if (PF) {
+#pragma unroll
+        for (int i = 0; i < A_PW; ++i) glds16(srcA[i] + t_begin * FT_BK, sA + (wave * A_PW + i) * 8 * FT_BK);
+#pragma unroll
+        for (int i = 0; i < B_PW; ++i) glds16(srcB[i] + t_begin * FT_BK, sB + (wave * B_PW + i) * 8 * FT_BK);
+    }
     for (int t = t_begin; t < nt; ++t) {
         const int k0 = t * FT_BK;
-        const bf16_t* cA = sA;
-        const bf16_t* cB = sB;
-        {
+        const int cur = PF ? ((t - t_begin) & 1) * STAGE : 0;
+        const bf16_t* cA = sA + cur;
+        const bf16_t* cB = sB + cur;
+        if (PF) {
+            __syncthreads();                                        // emits vmcnt(0): step t has landed; and every wave is done with the other stage
+            if (t + 1 < nt) {
+                const int nxt = STAGE - cur;
+#pragma unroll
+                for (int i = 0; i < A_PW; ++i) glds16(srcA[i] + k0 + FT_BK, sA + nxt + (wave * A_PW + i) * 8 * FT_BK);
+#pragma unroll
+                for (int i = 0; i < B_PW; ++i) glds16(srcB[i] + k0 + FT_BK, sB + nxt + (wave * B_PW + i) * 8 * FT_BK);
+            }
+        } else {
 #pragma unroll
             for (int i = 0; i < A_PW; ++i) glds16(srcA[i] + k0, sA + (wave * A_PW + i) * 8 * FT_BK);
 #pragma unroll
@@ -265,7 +288,7 @@ void gemm_nt_bf16_kernel(FastArgs g) {
                 for (int i = 0; i < MT; ++i)
                     acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[j][i], 0, 0, 0);
         }
-        __syncthreads();                                            // tile consumed before it is overwritten
+        if (NS == 1) __syncthreads();                               // tile consumed before it is overwritten
     }
 
     gemm_epilogue<TC, MT>(g, acc, m0 + wm, n0 + wn, lane, g.splitk > 1 ? g.ws + (long long)blockIdx.y * g.M * g.N : nullptr, 0);
@@ -899,9 +922,16 @@ static int launch_fast(const egomi_gemm_desc* d, FastArgs& g, hipStream_t s) {
         if (sk > 1) { const int per = (nt + sk - 1) / sk; sk = (nt + per - 1) / per; }     // no empty slices
         if (sk > 1) g.splitk = sk;
     }
-    if (d->c_dtype == EGOMI_BF16) EGOMI_LAUNCH((gemm_nt_bf16_kernel<bf16_t, BM, BN>), dim3(nwg, g.splitk), dim3(threads), 0, s, g);
-    else if (d->c_dtype == EGOMI_F32) EGOMI_LAUNCH((gemm_nt_bf16_kernel<float, BM, BN>), dim3(nwg, g.splitk), dim3(threads), 0, s, g);
-    else return EGOMI_E_UNSUPPORTED;
+    static int pf_env = -1;                                            // EGOMI_GEMM_PF=0: one LDS stage (A/B switch)
+    if (pf_env < 0) { const char* e = getenv("EGOMI_GEMM_PF"); pf_env = e ? atoi(e) : 1; }
+    if (d->c_dtype != EGOMI_BF16 && d->c_dtype != EGOMI_F32) return EGOMI_E_UNSUPPORTED;
+    if (BM == 128 && BN == 128 && pf_env) {
+        if constexpr (BM == 128 && BN == 128) {
+            if (d->c_dtype == EGOMI_BF16) EGOMI_LAUNCH((gemm_nt_bf16_kernel<bf16_t, 128, 128, 2>), dim3(nwg, g.splitk), dim3(threads), 0, s, g);
+            else EGOMI_LAUNCH((gemm_nt_bf16_kernel<float, 128, 128, 2>), dim3(nwg, g.splitk), dim3(threads), 0, s, g);
+        }
+    } else if (d->c_dtype == EGOMI_BF16) EGOMI_LAUNCH((gemm_nt_bf16_kernel<bf16_t, BM, BN, 1>), dim3(nwg, g.splitk), dim3(threads), 0, s, g);
+    else EGOMI_LAUNCH((gemm_nt_bf16_kernel<float, BM, BN, 1>), dim3(nwg, g.splitk), dim3(threads), 0, s, g);
     if (g.splitk > 1) {
         const long long total = (long long)d->M * ((d->N + 3) / 4);
         const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
