@@ -300,38 +300,41 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
         STAMP(2)                                                       // barrier A
         const unsigned long long kmask = __ballot(sMask[kv0 + lane] != 0);
 
-        if (!wave_dead) {
-        float s[2][16];
-        float mloc = -INFINITY;
-        // causal: a 32-key sub-tile that starts beyond the wave's last query is masked for every lane -> no MFMAs
+        // causal: a 32-key sub-tile that starts beyond the wave's last query is masked for every lane -> nothing to do for it
         const int wave_qmax = q0 + wave * 32 + 31;
+        const bool live0 = !wave_dead && (!a.causal || kv0 <= wave_qmax);                  // wave-uniform; live1 implies live0
+        const bool live1 = !wave_dead && (!a.causal || kv0 + 32 <= wave_qmax);
+        if (live0) {
+        // Order inside a tile-step: both score chains are ISSUED before anything reads a score (the max of sub-tile 0 runs
+        // under the MFMAs of sub-tile 1), and the exponentials of sub-tile 1 come after the P.V MFMAs of sub-tile 0 were
+        // issued — MFMAs execute asynchronously, so independent VALU work placed behind them in program order overlaps them.
+        f32x16 x[2];
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
-            const bool live = !a.causal || (kv0 + 32 * sub <= wave_qmax);          // wave-uniform
-            if (!live) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) s[sub][r] = -INFINITY;
-                continue;
-            }
-            f32x16 x;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) x[r] = 0.f;
+            for (int r = 0; r < 16; ++r) x[sub][r] = 0.f;
+            if (sub == 1 && !live1) continue;
 #pragma unroll
             for (int ks = 0; ks < HD / 16; ++ks)
-                x = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_row8_t<HD>(sK, 32 * sub + (lane & 31), 2 * ks + half), qf[ks], x, 0, 0, 0);
-            // raw scores stay in s[][] (the scale is folded into the exp); masks only where the sub-tile needs them
+                x[sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_row8_t<HD>(sK, 32 * sub + (lane & 31), 2 * ks + half), qf[ks], x[sub], 0, 0, 0);
+        }
+        float mloc = -INFINITY;
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            if (sub == 1 && !live1) continue;
+            // raw scores stay in x[][] (the scale is folded into the exp); masks only where the sub-tile needs them
             const bool interior = ((kmask >> (32 * sub)) & 0xFFFFFFFFull) == 0xFFFFFFFFull &&
                                   (!a.causal || kv0 + 32 * sub + 31 <= q0 + wave * 32);       // wave-uniform
             if (interior) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) { s[sub][r] = x[r]; mloc = fmaxf(mloc, x[r]); }
+                for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, x[sub][r]);
             } else {
                 asm volatile("");                                          // keeps the two paths apart (otherwise merged into selects)
                 const uint32_t vis = visible_bits((uint32_t)(kmask >> (32 * sub)), half, kv0 + 32 * sub, qi, a.causal);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const float v = (vis >> rowmap(r, 0)) & 1u ? x[r] : -INFINITY;
-                    s[sub][r] = v;
+                    const float v = (vis >> rowmap(r, 0)) & 1u ? x[sub][r] : -INFINITY;
+                    x[sub][r] = v;
                     mloc = fmaxf(mloc, v);
                 }
             }
@@ -343,34 +346,43 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
         const float alpha = m_run == -INFINITY ? 0.f : fast_exp2(m_run - m_safe);
         float lsum = 0.f;
 #pragma unroll
-        for (int sub = 0; sub < 2; ++sub)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float p = fast_exp2(fmaf(s[sub][r], sc2, -m_safe));  // exp2(-inf) = 0 for masked keys
-                s[sub][r] = p;
-                lsum += p;
-            }
-        lsum += __shfl_xor(lsum, 32, 64);
-        l_run = l_run * alpha + lsum;
-        m_run = m_new;
+        for (int r = 0; r < 16; ++r) {
+            const float p = fast_exp2(fmaf(x[0][r], sc2, -m_safe));   // exp2(-inf) = 0 for masked keys
+            x[0][r] = p;
+            lsum += p;
+        }
         if (!__all(alpha == 1.0f)) {                                   // running max unchanged for the whole wave: O keeps its scale
 #pragma unroll
             for (int dt = 0; dt < HD / 32; ++dt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
         }
-        STAMP(4)                                                       // softmax
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
-            if (a.causal && (kv0 + 32 * sub > wave_qmax)) continue;                  // P is all zero there
+            if (sub == 1) {
+                if (!live1) continue;                                  // P is all zero there
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float p = fast_exp2(fmaf(x[1][r], sc2, -m_safe));
+                    x[1][r] = p;
+                    lsum += p;
+                }
+            }
 #pragma unroll
             for (int st = 0; st < 2; ++st) {
-                const bf16x8 pb = pack8(&s[sub][8 * st]);
+                float pv8[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) pv8[j] = x[sub][8 * st + j];
+                const bf16x8 pb = pack8(pv8);
 #pragma unroll
                 for (int dt = 0; dt < HD / 32; ++dt)
                     o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_tr8_t<HD>(sV, 32 * sub + 16 * st, 32 * dt, lane), pb, o[dt], 0, 0, 0);
             }
         }
+        STAMP(4)                                                       // softmax + PV
+        lsum += __shfl_xor(lsum, 32, 64);
+        l_run = l_run * alpha + lsum;
+        m_run = m_new;
         STAMP(5)                                                       // PV issue
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
