@@ -196,6 +196,7 @@ static int launch_generic(const egomi_gemm_desc* d, hipStream_t s) {
 }
 
 int egomi_gemm_fast_try(const egomi_gemm_desc* d, hipStream_t s);   // gemm_fast.hip; returns 1 if not applicable
+extern thread_local hipEvent_t egomi_time_start_, egomi_time_stop_;  // api.hip
 
 extern "C" int egomi_gemm(const egomi_gemm_desc* d, egomi_stream_t stream) {
     if (!d || !d->A || !d->B || !d->C) return EGOMI_E_BADARG;
@@ -208,6 +209,8 @@ extern "C" int egomi_gemm(const egomi_gemm_desc* d, egomi_stream_t stream) {
     if (!d->force_generic) {
         const int r = egomi_gemm_fast_try(d, s);
         if (r <= 0) return r;
+    } else {
+        egomi_time_start_ = egomi_time_stop_ = nullptr;               // egomi_gemm_time_next: consumed by this call whatever path it takes
     }
     if (d->ab_dtype == EGOMI_F32 && d->c_dtype == EGOMI_F32) return launch_generic<float, float>(d, s);
     if (d->ab_dtype == EGOMI_BF16 && d->c_dtype == EGOMI_BF16) return launch_generic<bf16_t, bf16_t>(d, s);

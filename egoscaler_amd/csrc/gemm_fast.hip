@@ -1038,7 +1038,7 @@ static int launch_p8(const egomi_gemm_desc* d, FastArgs& g, const P8Sched& sc, h
     return egomi_launch_status();
 }
 
-static int launch_8phase(const egomi_gemm_desc* d, FastArgs& g, hipStream_t s, int* tickets = nullptr) {
+static int launch_8phase(const egomi_gemm_desc* d, FastArgs& g, hipStream_t s, int* tickets = nullptr, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr) {
     g.tiles_m = (d->M + 255) / 256; g.tiles_n = (d->N + 255) / 256;
     g.splitk = 1; g.ws = (float*)d->workspace;
     static int no_tail = -1;
@@ -1063,9 +1063,11 @@ static int launch_8phase(const egomi_gemm_desc* d, FastArgs& g, hipStream_t s, i
     g.tickets = nullptr;
     if (tp.rows && tickets && tp.rows * g.tiles_n <= 1024 && (long long)tp.rows * g.tiles_n * tp.s * 262144 <= d->workspace_bytes) g.tickets = tickets;
     const int nwg = g.full_tiles + tp.rows * g.tiles_n * tp.s;
+    if (d->c_dtype != EGOMI_BF16 && d->c_dtype != EGOMI_F32) return EGOMI_E_UNSUPPORTED;
+    if (t0) (void)hipEventRecord(t0, s);                                 // egomi_gemm_time_next: this kernel alone
     if (d->c_dtype == EGOMI_BF16) EGOMI_LAUNCH(gemm_nt_bf16_8phase_kernel<bf16_t>, dim3(nwg, 1), dim3(512), 0, s, g);
-    else if (d->c_dtype == EGOMI_F32) EGOMI_LAUNCH(gemm_nt_bf16_8phase_kernel<float>, dim3(nwg, 1), dim3(512), 0, s, g);
-    else return EGOMI_E_UNSUPPORTED;
+    else EGOMI_LAUNCH(gemm_nt_bf16_8phase_kernel<float>, dim3(nwg, 1), dim3(512), 0, s, g);
+    if (t1) (void)hipEventRecord(t1, s);
     if (tp.rows && g.epi == 1 && g.tickets) g.tickets = nullptr;         // the fused SwiGLU epilogue wants the separate combine + tail pass below
     if (tp.rows && !g.tickets) {
         FastArgs r = g;
@@ -1087,7 +1089,11 @@ static int launch_8phase(const egomi_gemm_desc* d, FastArgs& g, hipStream_t s, i
 }
 
 // returns 0 on success, <0 on error, 1 when the tuned kernel does not apply
+extern thread_local hipEvent_t egomi_time_start_, egomi_time_stop_;     // api.hip (egomi_gemm_time_next)
+
 int egomi_gemm_fast_try(const egomi_gemm_desc* d0, hipStream_t s) {
+    const hipEvent_t t0 = egomi_time_start_, t1 = egomi_time_stop_;       // one-shot request: consumed by this call whatever path it takes
+    egomi_time_start_ = egomi_time_stop_ = nullptr;
     if (!fast_applicable(d0)) return 1;
     egomi_gemm_desc dl = *d0;
     const egomi_gemm_desc* d = &dl;
@@ -1108,7 +1114,7 @@ int egomi_gemm_fast_try(const egomi_gemm_desc* d0, hipStream_t s) {
             if (dl.workspace_bytes > 4096) { dl.workspace = (char*)dl.workspace + 4096; dl.workspace_bytes -= 4096; }
             else { dl.workspace = nullptr; dl.workspace_bytes = 0; }
         }
-        return launch_8phase(d, g, s, nullptr);
+        return launch_8phase(d, g, s, nullptr, t0, t1);
     }
     if (tc == 8 && (long long)d->M * d->lda < (1ll << 31) && (long long)d->N * d->ldb < (1ll << 31)) {
         P8Sched sc;
@@ -1128,6 +1134,6 @@ int egomi_gemm_fast_try(const egomi_gemm_desc* d0, hipStream_t s) {
     static int fold = -1;
     if (fold < 0) { const char* e = getenv("EGOMI_GEMM_FOLD"); fold = e ? atoi(e) : 0; }
     if (!fold && dl.ws_tickets_zeroed != 2) tickets = nullptr;
-    if (tc == 8 && (long long)d->M * d->lda < (1ll << 31) && (long long)d->N * d->ldb < (1ll << 31)) return launch_8phase(d, g, s, tickets);
+    if (tc == 8 && (long long)d->M * d->lda < (1ll << 31) && (long long)d->N * d->ldb < (1ll << 31)) return launch_8phase(d, g, s, tickets, t0, t1);
     return tc == 2 ? launch_fast<256, 128>(d, g, s) : launch_fast<128, 128>(d, g, s);
 }

@@ -146,13 +146,33 @@ class GemmProfiler:
         self.kernel_ids = kernel_ids if kernel_ids is not None else ((1, 2) if tuned_only else None)
 
     def summary(self):
+        """launches / flops / ms: the recorded brackets.  For launches of the 256x256 kernel (kernel id 2) `ms` is that kernel alone
+        (events recorded by the library around it: egomi_gemm_time_next) and `call_ms` the whole egomi_gemm call, i.e. including
+        the slab-combine pass of K-sliced tail rows; for other kernels both are the call."""
         torch.cuda.synchronize()
-        n, flops, ms = 0, 0.0, 0.0
-        for e0, e1, f in self.recs:
+        n, flops, ms, call_ms = 0, 0.0, 0.0, 0.0
+        L = _lib.lib()
+        for e0, e1, f, k0, k1 in self.recs:
             n += 1
             flops += f
-            ms += e0.elapsed_time(e1)
-        return {"launches": n, "flops": flops, "ms": ms}
+            c = e0.elapsed_time(e1)
+            call_ms += c
+            if k0 is not None:
+                t = ctypes.c_float()
+                ms += t.value if L.egomi_event_elapsed_ms(k0, k1, ctypes.byref(t)) == 0 else c     # never recorded (opt-in persistent form): the call
+            else:
+                ms += c
+        return {"launches": n, "flops": flops, "ms": ms, "call_ms": call_ms}
+
+    def __del__(self):
+        try:
+            L = _lib.lib()
+            for _, _, _, k0, k1 in self.recs:
+                if k0 is not None:
+                    L.egomi_event_destroy(k0)
+                    L.egomi_event_destroy(k1)
+        except Exception:
+            pass
 
 
 PROFILER = None
@@ -207,13 +227,20 @@ def gemm_raw(A, B, C, M, N, K, lda, ldb, ldc, a_layout=0, b_layout=0, bias=None,
             raise _lib.EgomiError("gemm needs device tensors")
     prof = PROFILER
     flops = 2.0 * M * N * K * max(1, batch)
-    if prof is not None and prof.enabled and flops >= prof.min_flops and \
-            (prof.kernel_ids is None or _lib.lib().egomi_gemm_kernel_id(ctypes.byref(d)) in prof.kernel_ids):
+    kid = _lib.lib().egomi_gemm_kernel_id(ctypes.byref(d)) if (prof is not None and prof.enabled and flops >= prof.min_flops) else None
+    if kid is not None and (prof.kernel_ids is None or kid in prof.kernel_ids):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        k0 = k1 = None
+        if kid == 2:                                        # the 256x256 kernel: the library brackets the kernel itself
+            L = _lib.lib()
+            k0, k1 = c_p(), c_p()
+            _lib.check(L.egomi_event_create(ctypes.byref(k0)), "egomi_event_create")
+            _lib.check(L.egomi_event_create(ctypes.byref(k1)), "egomi_event_create")
+            _lib.check(L.egomi_gemm_time_next(k0, k1), "egomi_gemm_time_next")
         e0.record()
         call("egomi_gemm", ctypes.byref(d), S())
         e1.record()
-        prof.recs.append((e0, e1, flops))
+        prof.recs.append((e0, e1, flops, k0, k1))
     else:
         call("egomi_gemm", ctypes.byref(d), S())
     return C

@@ -152,6 +152,15 @@ int egomi_gemm(const egomi_gemm_desc* desc, egomi_stream_t stream);
 /* which kernel egomi_gemm would run for this descriptor: 2 = 256x256 8-phase bf16 NT kernel (either form), 1 = 128x128 / 256x128 bf16
  * NT kernel, 0 = generic */
 int egomi_gemm_kernel_id(const egomi_gemm_desc* desc);
+/* Measurement hooks (bench.py `roofline`; no reference counterpart).  egomi_gemm_time_next(start, stop): the NEXT egomi_gemm call
+ * of this thread, if it takes the 256x256 kernel (egomi_gemm_kernel_id == 2), records `start` right before and `stop` right after
+ * THAT kernel on the launch stream — the slab-combine pass of K-sliced tail rows is a separate kernel and lies outside the
+ * bracket; any other path leaves both events untouched.  The request is consumed by that call either way.  Events come from
+ * egomi_event_create (timing-enabled HIP events); egomi_event_elapsed_ms waits for `stop`. */
+int egomi_event_create(void** event);
+int egomi_event_destroy(void* event);
+int egomi_event_elapsed_ms(void* start, void* stop, float* ms);
+int egomi_gemm_time_next(void* start, void* stop);
 
 /* ------------------------------------------------------------------------------------------------
  * Fused attention (bf16, head_dim 128; forward also head_dim 64): softmax(scale * Q.K^T + mask).V without materialising the

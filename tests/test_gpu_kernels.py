@@ -362,6 +362,39 @@ def test_gemm_8phase_kernel(ops, M, N, K):
     assert torch.equal(x1, x2)
 
 
+def test_gemm_time_next_brackets_the_256_kernel_alone(ops):
+    """egomi_gemm_time_next (include/egomi.h): the library records the two events around the 256x256 kernel itself — shorter than
+    the call when the tail rows are K-sliced (separate combine pass), one-shot, untouched by other kernels."""
+    torch.manual_seed(0)
+    A = torch.randn(5536, 4096, device="cuda").bfloat16()
+    W = (torch.randn(4096, 4096, device="cuda") * 0.02).bfloat16()
+    prof = ops.GemmProfiler(min_flops=0, kernel_ids=(1, 2))
+    ops.PROFILER = prof
+    try:
+        for _ in range(3):
+            ops.mm(A, W)                                                   # kernel id 2 (+ combine of the sliced tail rows)
+        ops.mm(A[:256], W)                                                 # kernel id 1: no library events, the call is the bracket
+    finally:
+        ops.PROFILER = None
+    assert [r[3] is not None for r in prof.recs] == [True, True, True, False]
+    sm = prof.summary()
+    assert sm["launches"] == 4 and 0 < sm["ms"] < sm["call_ms"]
+    # one-shot: a request made before a call that takes another kernel is consumed by that call and never fires later
+    import ctypes
+    from egoscaler_amd import _lib
+    L = _lib.lib()
+    k0, k1 = ctypes.c_void_p(), ctypes.c_void_p()
+    assert L.egomi_event_create(ctypes.byref(k0)) == 0 and L.egomi_event_create(ctypes.byref(k1)) == 0
+    assert L.egomi_gemm_time_next(k0, k1) == 0
+    ops.mm(A[:256], W)
+    ops.mm(A, W)
+    torch.cuda.synchronize()
+    t = ctypes.c_float()
+    assert L.egomi_event_elapsed_ms(k0, k1, ctypes.byref(t)) != 0          # never recorded
+    assert L.egomi_gemm_time_next(k0, None) != 0                           # both or neither
+    L.egomi_event_destroy(k0); L.egomi_event_destroy(k1)
+
+
 @pytest.mark.parametrize("M,N,K", [(5536, 4096, 4096), (5536, 12288, 4096), (2900, 4100, 2048), (4096, 4096, 2048), (1500, 8200, 4224),
                                    (5536, 4096, 11008), (3000, 3000, 2112)])
 def test_gemm_persistent_8phase_kernel(ops, M, N, K):
