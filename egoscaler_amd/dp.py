@@ -57,8 +57,12 @@ class GradSync:
     reduced on a side stream as soon as they close; `finish()` joins.  wire_dtype=torch.bfloat16: buckets of at least
     `wire_min_bytes` cross the fabric as bf16 with fp32 accumulation (see the module docstring)."""
 
-    def __init__(self, group=None, wire_dtype=None, wire_min_bytes=32 << 20, bucket_bytes=1 << 30, run_single=False):
-        """run_single=True: a one-rank group still goes through every collective (tests drive the real RCCL backend that way
+    def __init__(self, group=None, wire_dtype=None, wire_min_bytes=32 << 20, bucket_bytes=256 << 20, run_single=False):
+        """bucket_bytes: loose tensors are packed until the open bucket reaches this size.  256 MB: in frozen-LLM mode the lm_head
+        gradient (0.53 GB, final at the very START of backward) closes its own bucket at once and crosses the fabric under the 32
+        layers' backward; with 1 GB it sat in the open bucket until the embedding gradient arrived at the end of backward and
+        both were reduced exposed.
+        run_single=True: a one-rank group still goes through every collective (tests drive the real RCCL backend that way
         on a one-GPU box; RCCL refuses two ranks on one device)."""
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
