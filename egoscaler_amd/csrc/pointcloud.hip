@@ -330,15 +330,34 @@ extern "C" int egomi_pc_norm(const double* points, const float* colors, float* o
 // =================================================================================================
 #define FPS_THREADS 1024
 
-__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long k) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        unsigned lo = __shfl_xor((unsigned)(k & 0xFFFFFFFFu), o, 64);
-        unsigned hi = __shfl_xor((unsigned)(k >> 32), o, 64);
-        unsigned long long other = ((unsigned long long)hi << 32) | lo;
-        k = other > k ? other : k;
-    }
+// Wave-wide max of a 64-bit key by DPP row operations (gfx9 scan sequence: row_shr 1,2,4,8 inside the rows of 16, then
+// row_bcast15 / row_bcast31 across rows); lanes that receive nothing see the identity 0.  The total ends in lane 63 and is
+// returned wave-uniform (v_readlane).  A ds_bpermute butterfly (12 LDS-crossbar round trips for 64 bits) was the longest
+// stretch of the FPS iteration's critical path.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned long long dpp_max_step(unsigned long long k) {
+    const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(k & 0xFFFFFFFFu), CTRL, ROW_MASK, 0xF, false);
+    const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(k >> 32), CTRL, ROW_MASK, 0xF, false);
+    const unsigned long long other = ((unsigned long long)hi << 32) | lo;
+    return other > k ? other : k;
+}
+__device__ __forceinline__ unsigned long long row16_max_u64(unsigned long long k) {      // total of each row of 16 in its last lane
+    k = dpp_max_step<0x111, 0xF>(k);
+    k = dpp_max_step<0x112, 0xF>(k);
+    k = dpp_max_step<0x114, 0xF>(k);
+    k = dpp_max_step<0x118, 0xF>(k);
     return k;
+}
+__device__ __forceinline__ unsigned long long readlane_u64(unsigned long long k, int lane) {
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(k & 0xFFFFFFFFu), lane);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(k >> 32), lane);
+    return ((unsigned long long)hi << 32) | lo;
+}
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long k) {
+    k = row16_max_u64(k);
+    k = dpp_max_step<0x142, 0xA>(k);                               // row_bcast15 -> rows 1 and 3
+    k = dpp_max_step<0x143, 0xC>(k);                               // row_bcast31 -> rows 2 and 3
+    return readlane_u64(k, 63);
 }
 
 template <int PPT>
@@ -386,14 +405,8 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(const float* pts, int 
         unsigned long long* sl = slots + (i & 1) * 16;
         if ((tid & 63) == 0) sl[tid >> 6] = best;
         __syncthreads();
-        unsigned long long k = sl[tid & 15];
-#pragma unroll
-        for (int o = 8; o > 0; o >>= 1) {
-            unsigned lo = __shfl_xor((unsigned)(k & 0xFFFFFFFFu), o, 64);
-            unsigned hi = __shfl_xor((unsigned)(k >> 32), o, 64);
-            unsigned long long other = ((unsigned long long)hi << 32) | lo;
-            k = other > k ? other : k;
-        }
+        // the 16 wave results: one per lane of row 0, reduced inside that row, read back from its last lane
+        const unsigned long long k = readlane_u64(row16_max_u64(sl[tid & 15]), 15);
         far = (int)(0xFFFFFFFFu - (unsigned)(k & 0xFFFFFFFFu));            // misc.py:59, lowest index on ties
     }
 }
