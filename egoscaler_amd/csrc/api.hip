@@ -38,7 +38,11 @@ extern "C" int egomi_event_elapsed_ms(void* start, void* stop, float* ms) {
     if (!start || !stop || !ms) return EGOMI_E_BADARG;
     hipError_t rc = hipEventSynchronize((hipEvent_t)stop);
     if (rc == hipSuccess) rc = hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop);
-    if (rc != hipSuccess) { egomi_last_hip_error_ = (int)rc; return EGOMI_E_LAUNCH; }
+    if (rc != hipSuccess) {                                          // e.g. an event that was never recorded
+        egomi_last_hip_error_ = (int)rc;
+        (void)hipGetLastError();                                     // do not leave the runtime's sticky error for the next caller to trip over
+        return EGOMI_E_LAUNCH;
+    }
     return EGOMI_OK;
 }
 extern "C" int egomi_gemm_time_next(void* start, void* stop) {
