@@ -894,6 +894,11 @@ static int tile_choice(const egomi_gemm_desc* d) {
     // enough tiles to occupy the chip at one block per CU and a K long enough to amortise its prologue/epilogue
     const long long t256 = (long long)((d->M + 255) / 256) * ((d->N + 255) / 256);
     if (t256 >= 128 && d->K >= 2048 && (long long)d->M * d->lda < (1ll << 31) && (long long)d->N * d->ldb < (1ll << 31)) return 8;
+    // few tiles but a very long K (the lm_head dgrad of the training step: 1280 x 4096 x 32320 = 80 tiles): every tile row K-sliced
+    // (plan_tail with rows = all) fills the chip — tools/debug/lmhead_dgrad_probe.py: 313 us (S = 6) vs 482 us on the 128x128 kernel
+    if (t256 >= 32 && t256 < 128 && d->K >= 8192 && d->M > 512 && d->epilogue == EGOMI_EPI_NONE && d->workspace &&
+        d->workspace_bytes >= (long long)((d->M + 255) / 256) * 256 * d->N * 4 * 2 + 4096 &&
+        (long long)d->M * d->lda < (1ll << 31) && (long long)d->N * d->ldb < (1ll << 31)) return 8;
     return (d->M >= 2048 && d->N >= 8192) ? 2 : 1;
 }
 
@@ -972,8 +977,9 @@ static TailPlan plan_tail(int M, int N, int K, long long ws_bytes) {
     TailPlan best = {0, 1};
     double tbest = model(0, 1);
     const double t0 = tbest;
+    const int smax = (long long)tm * tn < 128 ? 8 : 4;                // few tiles, long K: finer slices (every row sliced)
     for (int rows = 1; rows <= tm && rows <= 8; ++rows)
-        for (int S = 2; S <= 4; ++S) {
+        for (int S = 2; S <= smax; ++S) {
             if (nt / S < 8) continue;
             if ((long long)(M - (tm - rows) * 256) * N * 4 * S > ws_bytes) continue;
             const double t = model(rows, S);
