@@ -151,6 +151,153 @@ extern "C" int egomi_attn_decode(const void* q, int64_t ld_q, const void* kcache
 }
 
 // ------------------------------------------------------------------------------------------------
+// Consumers of EGOMI_EPI_SLABS products (include/egomi.h): the single-token step's split-K projections leave fp32 K-slice
+// slabs; these kernels sum them (slice order, like splitk_reduce_kernel) while doing the next operation of the layer, with
+// the rounding sequence of the separate kernels they replace (bit-identical results).
+//
+// slabs_rmsnorm: x = bf16(sum_s slab[s] + residual)   (the o_proj / down_proj output with its residual, HF modeling_llama.py:
+//                 243-281), h = rmsnorm(x) * w         (rmsnorm_fwd_kernel's arithmetic).  One 256-thread block per row.
+// ------------------------------------------------------------------------------------------------
+template <typename T, int MAXV>
+__global__ __launch_bounds__(256) void slabs_rmsnorm_kernel(const float* slabs, int sk, long long slab_stride, int cols, const T* residual, long long ldr,
+                                                            const T* w, float eps, T* x_out, long long ldx, T* h_out, long long ldh) {
+    __shared__ float red[16];
+    const long long row = blockIdx.x;
+    float xv[MAXV][8];
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = (threadIdx.x + i * 256) * 8;
+        if (c < cols) {
+            float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            for (int s2 = 0; s2 < sk; ++s2) {
+                float t[8];
+                load8<float>(slabs + (long long)s2 * slab_stride + row * cols + c, t);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] += t[j];
+            }
+            if (residual) {
+                float r[8];
+                load8<T>(residual + row * ldr + c, r);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] += r[j];
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) xv[i][j] = sizeof(T) == 2 ? bf2f(f2bf(v[j])) : v[j];      // what the combine pass would have stored
+            store8<T>(x_out + row * ldx + c, xv[i]);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) ss += xv[i][j] * xv[i][j];
+        }
+    }
+    const float rstd = rsqrtf(block_sum(ss, red) / cols + eps);
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = (threadIdx.x + i * 256) * 8;
+        if (c < cols) {
+            float ww[8], o[8];
+            load8<T>(w + c, ww);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float h = xv[i][j] * rstd;
+                if (sizeof(T) == 2) h = bf2f(f2bf(h));
+                o[j] = ww[j] * h;
+            }
+            store8<T>(h_out + row * ldh + c, o);
+        }
+    }
+}
+
+extern "C" int egomi_slabs_rmsnorm(const float* slabs, int slices, int rows, int cols, const void* residual, int64_t ldr, const void* w, float eps,
+                                   void* x_out, int64_t ldx, void* h_out, int64_t ldh, int dtype, egomi_stream_t stream) {
+    if (!slabs || !w || !x_out || !h_out) return EGOMI_E_BADARG;
+    if (slices < 1 || rows <= 0 || cols <= 0 || cols % 8 || ldx < cols || ldh < cols || ldx % 8 || ldh % 8 || (residual && (ldr < cols || ldr % 8))) return EGOMI_E_SHAPE;
+    if (cols > 8192) return EGOMI_E_UNSUPPORTED;
+    if (((uintptr_t)slabs | (uintptr_t)x_out | (uintptr_t)h_out | (uintptr_t)w | (uintptr_t)residual) & 15) return EGOMI_E_SHAPE;
+    hipStream_t s = (hipStream_t)stream;
+    const long long stride = (long long)rows * cols;
+#define SRN(V) EGOMI_DISPATCH_DTYPE(dtype, EGOMI_LAUNCH((slabs_rmsnorm_kernel<T, V>), dim3(rows), dim3(256), 0, s, slabs, slices, stride, cols, (const T*)residual, \
+                                                        (long long)ldr, (const T*)w, eps, (T*)x_out, (long long)ldx, (T*)h_out, (long long)ldh))
+    if (cols <= 2048) SRN(1); else if (cols <= 4096) SRN(2); else SRN(4);
+#undef SRN
+    return egomi_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------
+// qkv_finish (single-token step): q|k|v = bf16(sum_s slab[s]) [B, 3*H*hd]; RoPE at position `pos` on q and k (rope_vec8_kernel's
+// arithmetic, HF apply_rotary_pos_emb), q written to qkv (attn_decode reads it there), k and v written straight into the
+// [B,H,Smax,hd] caches at `pos`.  Replaces splitk_reduce + rope + kv_append.  One thread per 8 rotation pairs / 16 v columns.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void qkv_finish_kernel(const float* slabs, int sk, long long slab_stride, T* qkv, long long ld, const float* cos_tab,
+                                                         const float* sin_tab, int pos, T* kc, T* vc, int B, int H, int hd, int Smax) {
+    const int half = hd >> 1, cpv = half >> 3;
+    const long long total = (long long)B * 3 * H * cpv;
+    const long long d = (long long)H * hd;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const int i = (int)(e % cpv) * 8;
+        const int h = (int)((e / cpv) % H);
+        const int part = (int)((e / ((long long)cpv * H)) % 3);
+        const long long b = e / ((long long)cpv * H * 3);
+        const long long col = part * d + (long long)h * hd + i;
+        float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, bb[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int s2 = 0; s2 < sk; ++s2) {
+            float t[8];
+            load8<float>(slabs + (long long)s2 * slab_stride + b * 3 * d + col, t);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) a[j] += t[j];
+            load8<float>(slabs + (long long)s2 * slab_stride + b * 3 * d + col + half, t);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) bb[j] += t[j];
+        }
+        if (sizeof(T) == 2) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { a[j] = bf2f(f2bf(a[j])); bb[j] = bf2f(f2bf(bb[j])); }       // the product as the combine pass would have stored it
+        }
+        float oa[8], ob[8];
+        if (part < 2) {
+            float c[8], sn[8];
+            load8<float>(cos_tab + (long long)pos * half + i, c);
+            load8<float>(sin_tab + (long long)pos * half + i, sn);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float cj = c[j], sj = sn[j];
+                if (sizeof(T) == 2) {
+                    cj = bf2f(f2bf(cj)); sj = bf2f(f2bf(sj));
+                    oa[j] = bf2f(f2bf(a[j] * cj)) + bf2f(f2bf(-bb[j] * sj));
+                    ob[j] = bf2f(f2bf(bb[j] * cj)) + bf2f(f2bf(a[j] * sj));
+                } else {
+                    oa[j] = a[j] * cj + (-bb[j]) * sj;
+                    ob[j] = bb[j] * cj + a[j] * sj;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { oa[j] = a[j]; ob[j] = bb[j]; }
+        }
+        if (part == 0) {
+            store8<T>(qkv + b * ld + col, oa);
+            store8<T>(qkv + b * ld + col + half, ob);
+        } else {
+            T* dst = (part == 1 ? kc : vc) + ((b * H + h) * Smax + pos) * hd + i;
+            store8<T>(dst, oa);
+            store8<T>(dst + half, ob);
+        }
+    }
+}
+
+extern "C" int egomi_qkv_finish(const float* slabs, int slices, void* qkv, int64_t ld, const float* cos_tab, const float* sin_tab, int pos,
+                                void* kcache, void* vcache, int B, int H, int hd, int Smax, int dtype, egomi_stream_t stream) {
+    if (!slabs || !qkv || !cos_tab || !sin_tab || !kcache || !vcache) return EGOMI_E_BADARG;
+    if (slices < 1 || B <= 0 || H <= 0 || hd <= 0 || (hd / 2) % 8 || ld % 8 || ld < 3ll * H * hd || pos < 0 || pos >= Smax) return EGOMI_E_SHAPE;
+    if (((uintptr_t)slabs | (uintptr_t)qkv | (uintptr_t)kcache | (uintptr_t)vcache | (uintptr_t)cos_tab | (uintptr_t)sin_tab) & 15) return EGOMI_E_SHAPE;
+    const long long total = (long long)B * 3 * H * (hd / 16);
+    const int grid = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    EGOMI_DISPATCH_DTYPE(dtype, EGOMI_LAUNCH(qkv_finish_kernel<T>, dim3(grid), dim3(256), 0, (hipStream_t)stream, slabs, slices, (long long)B * 3 * H * hd,
+                                             (T*)qkv, (long long)ld, cos_tab, sin_tab, pos, (T*)kcache, (T*)vcache, B, H, hd, Smax));
+    return egomi_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------
 // greedy step: ids[b] = argmax_v logits[b, v] (lowest index on ties, like torch.argmax on CPU/GPU for
 // distinct values); also stored at seq[b * ld_seq + pos] when seq != NULL.
 // ------------------------------------------------------------------------------------------------

@@ -212,6 +212,7 @@ extern "C" int egomi_gemm(const egomi_gemm_desc* d, egomi_stream_t stream) {
     } else {
         egomi_time_start_ = egomi_time_stop_ = nullptr;               // egomi_gemm_time_next: consumed by this call whatever path it takes
     }
+    if (d->epilogue != EGOMI_EPI_NONE) return EGOMI_E_UNSUPPORTED;   // fused epilogues exist in the tuned kernels only: never drop one silently
     if (d->ab_dtype == EGOMI_F32 && d->c_dtype == EGOMI_F32) return launch_generic<float, float>(d, s);
     if (d->ab_dtype == EGOMI_BF16 && d->c_dtype == EGOMI_BF16) return launch_generic<bf16_t, bf16_t>(d, s);
     if (d->ab_dtype == EGOMI_BF16 && d->c_dtype == EGOMI_F32) return launch_generic<bf16_t, float>(d, s);

@@ -908,25 +908,38 @@ extern "C" int egomi_gemm_kernel_id(const egomi_gemm_desc* d) {
     return tile_choice(d) == 8 ? 2 : 1;
 }
 
+static bool slabs_form_ok(const egomi_gemm_desc* d);
+static int skinny_splitk(const egomi_gemm_desc* d, int nwg);
+extern "C" int egomi_gemm_slab_count(const egomi_gemm_desc* d) {
+    if (!d) return EGOMI_E_BADARG;
+    if (d->force_generic || !fast_applicable(d) || !slabs_form_ok(d) || tile_choice(d) != 1) return 0;
+    const int sk = skinny_splitk(d, ((d->M + 127) / 128) * ((d->N + 127) / 128));
+    return sk >= 2 ? sk : 0;
+}
+
+// skinny products (decode, M <= 512): too few tiles to fill 256 CUs and each block is DMA-latency bound, so the K range is
+// split over blockIdx.y into fp32 slabs (caller-provided workspace) and combined.  -> number of K-slices (1 = no split)
+static int skinny_splitk(const egomi_gemm_desc* d, int nwg) {
+    const int nt = d->K / FT_BK;
+    if (!(d->workspace && d->M <= 512 && nwg < 512)) return 1;
+    // measured (tools/gemm_bench_decode.py, M=256): ~256 blocks, and no more than ~32 K-steps per slice
+    int sk = d->split_k > 0 ? d->split_k : (nwg >= 256 ? 1 : (256 + nwg - 1) / nwg);
+    if (d->split_k <= 0 && sk > 1 && nt / sk > 32) sk *= 2;
+    if (sk > nt) sk = nt;
+    const long long per_slab = (long long)d->M * d->N * 4;
+    if ((long long)sk * per_slab > d->workspace_bytes) sk = (int)(d->workspace_bytes / per_slab);
+    if (sk > 1) { const int per = (nt + sk - 1) / sk; sk = (nt + per - 1) / per; }     // no empty slices
+    return sk > 1 ? sk : 1;
+}
+
 template <int BM, int BN>
 static int launch_fast(const egomi_gemm_desc* d, FastArgs& g, hipStream_t s) {
     g.tiles_m = (d->M + BM - 1) / BM; g.tiles_n = (d->N + BN - 1) / BN;
     const int nwg = g.tiles_m * g.tiles_n;
     constexpr int threads = (BM / 64) * (BN / 64) * 64;
-    // skinny products (decode, M <= 512): too few tiles to fill 256 CUs and each block is DMA-latency bound,
-    // so the K range is split over blockIdx.y into fp32 slabs (caller-provided workspace) and combined
-    g.splitk = 1; g.ws = (float*)d->workspace;
-    const int nt = d->K / FT_BK;
-    if (d->workspace && d->M <= 512 && nwg < 512) {
-        // measured (tools/gemm_bench_decode.py, M=256): ~256 blocks, and no more than ~32 K-steps per slice
-        int sk = d->split_k > 0 ? d->split_k : (nwg >= 256 ? 1 : (256 + nwg - 1) / nwg);
-        if (d->split_k <= 0 && sk > 1 && nt / sk > 32) sk *= 2;
-        if (sk > nt) sk = nt;
-        const long long per_slab = (long long)d->M * d->N * 4;
-        if ((long long)sk * per_slab > d->workspace_bytes) sk = (int)(d->workspace_bytes / per_slab);
-        if (sk > 1) { const int per = (nt + sk - 1) / sk; sk = (nt + per - 1) / per; }     // no empty slices
-        if (sk > 1) g.splitk = sk;
-    }
+    g.ws = (float*)d->workspace;
+    g.splitk = skinny_splitk(d, nwg);
+    if (d->epilogue == EGOMI_EPI_SLABS && g.splitk < 2) return EGOMI_E_UNSUPPORTED;     // egomi_gemm_slab_count said so
     static int pf_env = -1;                                            // EGOMI_GEMM_PF=0: one LDS stage (A/B switch)
     if (pf_env < 0) { const char* e = getenv("EGOMI_GEMM_PF"); pf_env = e ? atoi(e) : 1; }
     if (d->c_dtype != EGOMI_BF16 && d->c_dtype != EGOMI_F32) return EGOMI_E_UNSUPPORTED;
@@ -937,7 +950,7 @@ static int launch_fast(const egomi_gemm_desc* d, FastArgs& g, hipStream_t s) {
         }
     } else if (d->c_dtype == EGOMI_BF16) EGOMI_LAUNCH((gemm_nt_bf16_kernel<bf16_t, BM, BN, 1>), dim3(nwg, g.splitk), dim3(threads), 0, s, g);
     else EGOMI_LAUNCH((gemm_nt_bf16_kernel<float, BM, BN, 1>), dim3(nwg, g.splitk), dim3(threads), 0, s, g);
-    if (g.splitk > 1) {
+    if (g.splitk > 1 && d->epilogue != EGOMI_EPI_SLABS) {                // EGOMI_EPI_SLABS: the caller's next kernel sums the slabs
         const long long total = (long long)d->M * ((d->N + 3) / 4);
         const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
         if (d->c_dtype == EGOMI_BF16) EGOMI_LAUNCH(splitk_reduce_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, g);
@@ -1095,6 +1108,11 @@ static int launch_8phase(const egomi_gemm_desc* d, FastArgs& g, hipStream_t s, i
 }
 
 // returns 0 on success, <0 on error, 1 when the tuned kernel does not apply
+// EGOMI_EPI_SLABS (include/egomi.h): plain product only — everything an epilogue could do is the consumer kernel's job
+static bool slabs_form_ok(const egomi_gemm_desc* d) {
+    return !d->bias && !d->residual && !d->accumulate && d->act == 0 && d->alpha == 1.0f && d->workspace && d->M <= 512 && (d->N & 3) == 0;
+}
+
 extern thread_local hipEvent_t egomi_time_start_, egomi_time_stop_;     // api.hip (egomi_gemm_time_next)
 
 int egomi_gemm_fast_try(const egomi_gemm_desc* d0, hipStream_t s) {
@@ -1109,6 +1127,15 @@ int egomi_gemm_fast_try(const egomi_gemm_desc* d0, hipStream_t s) {
     g.alpha = d->alpha; g.accumulate = d->accumulate; g.act = d->act; g.tickets = nullptr;
     g.epi = d->epilogue; g.C2 = d->C2; g.ldc2 = d->ldc2;
     const int tc = tile_choice(d);
+    if (d->epilogue == EGOMI_EPI_SLABS) {
+        if (!slabs_form_ok(d) || tc != 1) return EGOMI_E_UNSUPPORTED;
+        if (dl.ws_tickets_zeroed && dl.workspace) {                     // same scratch convention as below: slabs start behind the ticket words
+            if (dl.workspace_bytes > 4096) { dl.workspace = (char*)dl.workspace + 4096; dl.workspace_bytes -= 4096; }
+            else return EGOMI_E_UNSUPPORTED;
+        }
+        g.epi = 0;
+        return launch_fast<128, 128>(d, g, s);
+    }
     if (d->epilogue != EGOMI_EPI_NONE) {
         // fused epilogues live in the 256x256 per-tile kernel's plain-bf16 store path only: whole interleaved groups per wave
         // (N % 256 == 0), 16-B aligned rows, nothing else in the epilogue

@@ -9,6 +9,7 @@ on static buffers.  Every length is a launch argument, so T steps are captured i
 (BASELINE.json config 5) and replayed with a single launch; token ids never leave the device.
 """
 import ctypes
+import os
 
 import torch
 
@@ -57,6 +58,16 @@ class Decoder:
                      for l in range(L)]
         self.wgu = [engine.wgu[l] if l in engine.wgu else engine.stack_gate_up(w[f"model.layers.{l}.mlp.gate_proj.weight"], w[f"model.layers.{l}.mlp.up_proj.weight"])
                     for l in range(L)]                     # interleaved-32 rows when ffn % 32 == 0 (engine.gu_il): gate|up come out interleaved
+
+        # single-token step: the split-K projections leave their fp32 slabs unsummed and the NEXT kernel of the layer sums them
+        # while doing its own work (qkv -> RoPE + cache append; o_proj / down_proj -> residual + RMSNorm): three launches and a
+        # round trip of each product through HBM fewer per layer.  Slice counts are the library's plan for these shapes (0 =
+        # it would not split: that projection keeps the plain path).  EGOMI_DECODE_FUSED=0 switches the whole thing off (A/B).
+        self.fused = {"qkv": 0, "o": 0, "down": 0}
+        if T == torch.bfloat16 and os.environ.get("EGOMI_DECODE_FUSED", "1") != "0" and B <= 512:
+            self.fused["qkv"] = ops.mm_slabs(self.h, self.wqkv[0], self.qkv, self.gws, count_only=True)
+            self.fused["o"] = ops.mm_slabs(self.ao, w["model.layers.0.self_attn.o_proj.weight"], self.x_mid, self.gws, count_only=True)
+            self.fused["down"] = ops.mm_slabs(self.act, w["model.layers.0.mlp.down_proj.weight"], self.x, self.gws, count_only=True)
 
     # -- prefill -------------------------------------------------------------------------------------
     def _sink(self, l, qkv, B, Sq):
@@ -111,22 +122,42 @@ class Decoder:
         ops.embed_splice(self.tok, w["model.embed_tokens.weight"], None, None, eng.dims.pb.point_token_len, out=self.x.view(B, 1, d))
         x = self.x
         scale = hd ** -0.5
+        fq, fo, fd = self.fused["qkv"], self.fused["o"], self.fused["down"]
+        normed = False                                      # self.h already holds this layer's input norm (written by the previous layer's tail)
         for l in range(L):
             p = f"model.layers.{l}."
-            ops.rmsnorm(x, w[p + "input_layernorm.weight"], lm.rms_norm_eps, out=self.h)
-            ops.mm(self.h, self.wqkv[l], out=self.qkv, workspace=self.gws)
-            ops.rope_(self.qkv, eng.cos, eng.sin, B, 1, pos, 2 * H, hd, 3 * d)
-            kv_append(self.qkv[:, d:2 * d], self.qkv[:, 2 * d:], 3 * d, self.kc[l], self.vc[l], B, 1, H, hd, self.Smax, pos)
+            if not normed:
+                ops.rmsnorm(x, w[p + "input_layernorm.weight"], lm.rms_norm_eps, out=self.h)
+            if fq:
+                n = ops.mm_slabs(self.h, self.wqkv[l], self.qkv, self.gws)
+                ops.qkv_finish(self.gws, n, self.qkv, eng.cos, eng.sin, pos, self.kc[l], self.vc[l], B, H, hd, self.Smax)
+            else:
+                ops.mm(self.h, self.wqkv[l], out=self.qkv, workspace=self.gws)
+                ops.rope_(self.qkv, eng.cos, eng.sin, B, 1, pos, 2 * H, hd, 3 * d)
+                kv_append(self.qkv[:, d:2 * d], self.qkv[:, 2 * d:], 3 * d, self.kc[l], self.vc[l], B, 1, H, hd, self.Smax, pos)
             attn_decode(self.qkv, 3 * d, self.kc[l], self.vc[l], self.mask, self.ao, B, H, hd, self.Smax, pos + 1, scale)
-            ops.mm(self.ao, w[p + "self_attn.o_proj.weight"], out=self.x_mid, residual=x, workspace=self.gws)
-            ops.rmsnorm(self.x_mid, w[p + "post_attention_layernorm.weight"], lm.rms_norm_eps, out=self.h2)
+            if fo:
+                n = ops.mm_slabs(self.ao, w[p + "self_attn.o_proj.weight"], self.x_mid, self.gws)
+                ops.slabs_rmsnorm(self.gws, n, x, w[p + "post_attention_layernorm.weight"], lm.rms_norm_eps, self.x_mid, self.h2)
+            else:
+                ops.mm(self.ao, w[p + "self_attn.o_proj.weight"], out=self.x_mid, residual=x, workspace=self.gws)
+                ops.rmsnorm(self.x_mid, w[p + "post_attention_layernorm.weight"], lm.rms_norm_eps, out=self.h2)
             ops.mm(self.h2, self.wgu[l], out=self.gu, workspace=self.gws)
             if eng.gu_il:
                 ops.swiglu_il(self.gu, self.act)
             else:
                 ops.swiglu(self.gu[:, :Fd], self.gu[:, Fd:], self.act)
-            ops.mm(self.act, w[p + "mlp.down_proj.weight"], out=x, residual=self.x_mid, workspace=self.gws)     # x is not an input of this product
-        ops.rmsnorm(x, w["model.norm.weight"], lm.rms_norm_eps, out=self.hn)
+            if fd:                                          # x is not an input of this product: the tail writes the new residual stream into it
+                n = ops.mm_slabs(self.act, w[p + "mlp.down_proj.weight"], x, self.gws)
+                last = l + 1 == L
+                ops.slabs_rmsnorm(self.gws, n, self.x_mid, w["model.norm.weight"] if last else w[f"model.layers.{l + 1}.input_layernorm.weight"],
+                                  lm.rms_norm_eps, x, self.hn if last else self.h)
+                normed = True
+            else:
+                ops.mm(self.act, w[p + "mlp.down_proj.weight"], out=x, residual=self.x_mid, workspace=self.gws)
+                normed = False
+        if not normed:
+            ops.rmsnorm(x, w["model.norm.weight"], lm.rms_norm_eps, out=self.hn)
         ops.mm(self.hn, w["lm_head.weight"], out=self.lg)
 
     def greedy(self, T_new, use_graph=True, keep_scores=True):

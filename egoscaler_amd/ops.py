@@ -192,7 +192,7 @@ def _tail_workspace(device, nbytes=(4096 + 256 * 2 * 262144)):
 
 def gemm_raw(A, B, C, M, N, K, lda, ldb, ldc, a_layout=0, b_layout=0, bias=None, residual=None, ldr=0,
              act=0, alpha=1.0, accumulate=False, batch=1, batch_inner=1, strides=(0, 0, 0, 0, 0, 0), force_generic=False,
-             workspace=None, split_k=0, persistent=None, swiglu_out=None):
+             workspace=None, split_k=0, persistent=None, swiglu_out=None, slabs=False, count_only=False):
     """C = act(alpha*A.B + bias) + residual (+C).  A/B/C are tensors whose data_ptr() is the first
     element of the (first) operand; all strides in elements.  See include/egomi.h."""
     if A.dtype != B.dtype:
@@ -225,6 +225,15 @@ def gemm_raw(A, B, C, M, N, K, lda, ldb, ldc, a_layout=0, b_layout=0, bias=None,
     for t in (A, B, C):
         if not t.is_cuda:
             raise _lib.EgomiError("gemm needs device tensors")
+    if slabs or count_only:                               # EGOMI_EPI_SLABS: K-slice slabs stay unsummed in `workspace`; -> their number
+        d.epilogue = 2
+        n = _lib.lib().egomi_gemm_slab_count(ctypes.byref(d))
+        if count_only:
+            return n
+        if n < 2:
+            raise _lib.EgomiError("gemm: the library would not split this product (egomi_gemm_slab_count == 0)")
+        call("egomi_gemm", ctypes.byref(d), S())
+        return n
     prof = PROFILER
     flops = 2.0 * M * N * K * max(1, batch)
     kid = _lib.lib().egomi_gemm_kernel_id(ctypes.byref(d)) if (prof is not None and prof.enabled and flops >= prof.min_flops) else None
@@ -264,6 +273,28 @@ def mm(a, b, out=None, a_layout=0, b_layout=0, out_dtype=None, **kw):
     res = kw.get("residual")
     return gemm_raw(a, b, out, M, N, K, _ld(a), _ld(b), _ld(out), a_layout, b_layout,
                     ldr=_ld(res) if res is not None else 0, **kw)
+
+
+def mm_slabs(a, b, out_like, workspace, count_only=False):
+    """a [M,K] . b[N,K]^T with M <= 512 as UNSUMMED fp32 K-slice slabs [slices, M, N] at the start of `workspace` (include/egomi.h,
+    EGOMI_EPI_SLABS); returns the number of slices (count_only: without launching; 0 = the library would not split it).
+    `out_like` [M,N] only lends its dtype / alignment to the descriptor, it is not written."""
+    M, K = a.shape
+    N = b.shape[0]
+    return gemm_raw(a, b, out_like, M, N, K, _ld(a), _ld(b), _ld(out_like), workspace=workspace, slabs=not count_only, count_only=count_only)
+
+
+def slabs_rmsnorm(workspace, slices, residual, w, eps, x_out, h_out):
+    """x_out = round(sum of the slabs + residual), h_out = rmsnorm(x_out) * w  (egomi_slabs_rmsnorm)."""
+    rows, cols = x_out.shape
+    call("egomi_slabs_rmsnorm", P(workspace), c_i(slices), c_i(rows), c_i(cols), P(residual), c_i64(_ld(residual) if residual is not None else 0), P(w),
+         c_f(eps), P(x_out), c_i64(_ld(x_out)), P(h_out), c_i64(_ld(h_out)), c_i(dt(x_out.dtype)), S())
+
+
+def qkv_finish(workspace, slices, qkv, cos, sin, pos, kc, vc, B, H, hd, Smax):
+    """q|k|v = round(sum of the slabs); RoPE(pos) on q and k; q -> qkv, k / v -> the caches at `pos`  (egomi_qkv_finish)."""
+    call("egomi_qkv_finish", P(workspace), c_i(slices), P(qkv), c_i64(_ld(qkv)), P(cos), P(sin), c_i(pos), P(kc), P(vc), c_i(B), c_i(H), c_i(hd),
+         c_i(Smax), c_i(dt(qkv.dtype)), S())
 
 
 # ------------------------------------------------------------------------------------------ rows

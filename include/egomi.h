@@ -143,15 +143,23 @@ typedef struct egomi_gemm_desc {
      * and C2 [M, N/2] (row stride ldc2) receives silu(gate)*up = what egomi_swiglu_il_fwd(C) would write, bit for bit
      * (replaces the separate pass over C of HF LlamaMLP.forward, modeling_llama.py:174-176).  bf16 output, N % 256 == 0, no
      * bias / residual / activation / alpha / accumulate, products large enough for the 256x256 kernel
-     * (egomi_gemm_kernel_id == 2); anything else returns EGOMI_E_UNSUPPORTED. */
+     * (egomi_gemm_kernel_id == 2); anything else returns EGOMI_E_UNSUPPORTED.
+     * EGOMI_EPI_SLABS: skinny split-K products (M <= 512, the single-token decode projections) leave their fp32 K-slice slabs
+     * [slices][M][N] (row stride N) in `workspace` UNSUMMED and never touch C: the caller's next kernel (egomi_slabs_rmsnorm,
+     * egomi_qkv_finish) sums them in slice order while doing its own work, which saves the combine pass and a round trip of the
+     * product through HBM.  Plain product only (no bias / residual / activation / alpha / accumulate; add the residual in the
+     * consumer), N % 4 == 0.  egomi_gemm_slab_count(desc) tells how many slices the library will write for this descriptor
+     * (0: it would not split this product — use EGOMI_EPI_NONE); a request it cannot honour returns EGOMI_E_UNSUPPORTED. */
     int epilogue; void* C2; int64_t ldc2;
 } egomi_gemm_desc;
 #define EGOMI_EPI_NONE 0
 #define EGOMI_EPI_SWIGLU 1
+#define EGOMI_EPI_SLABS 2
 int egomi_gemm(const egomi_gemm_desc* desc, egomi_stream_t stream);
 /* which kernel egomi_gemm would run for this descriptor: 2 = 256x256 8-phase bf16 NT kernel (either form), 1 = 128x128 / 256x128 bf16
  * NT kernel, 0 = generic */
 int egomi_gemm_kernel_id(const egomi_gemm_desc* desc);
+int egomi_gemm_slab_count(const egomi_gemm_desc* desc);   /* EGOMI_EPI_SLABS: slices egomi_gemm will leave for this descriptor, 0 = none */
 /* Measurement hooks (bench.py `roofline`; no reference counterpart).  egomi_gemm_time_next(start, stop): the NEXT egomi_gemm call
  * of this thread, if it takes the 256x256 kernel (egomi_gemm_kernel_id == 2), records `start` right before and `stop` right after
  * THAT kernel on the launch stream — the slab-combine pass of K-sliced tail rows is a separate kernel and lies outside the
@@ -191,6 +199,15 @@ typedef struct egomi_attn_desc {
 int egomi_attn_fwd(const egomi_attn_desc* desc, egomi_stream_t stream);
 int egomi_attn_bwd(const egomi_attn_desc* desc, egomi_stream_t stream);
 
+/* Consumers of EGOMI_EPI_SLABS products (single-token decode; replace splitk combine + the next elementwise kernels of
+ * HF LlamaDecoderLayer.forward, modeling_llama.py:243-281, with identical rounding).  slabs: fp32 [slices][rows][cols].
+ * egomi_slabs_rmsnorm: x_out = round(sum slabs + residual), h_out = rmsnorm(x_out) * w          (cols % 8 == 0, <= 8192)
+ * egomi_qkv_finish   : q|k|v = round(sum slabs) [B, 3*H*hd]; RoPE(pos) on q, k; q -> qkv (row stride ld), k, v -> caches
+ *                      [B,H,Smax,hd] at position pos */
+int egomi_slabs_rmsnorm(const float* slabs, int slices, int rows, int cols, const void* residual, int64_t ldr, const void* w, float eps,
+                        void* x_out, int64_t ldx, void* h_out, int64_t ldh, int dtype, egomi_stream_t stream);
+int egomi_qkv_finish(const float* slabs, int slices, void* qkv, int64_t ld, const float* cos_tab, const float* sin_tab, int pos,
+                     void* kcache, void* vcache, int B, int H, int hd, int Smax, int dtype, egomi_stream_t stream);
 /* ------------------------------------------------------------------------------------------------
  * A13  cached decoding.  replaces the past_key_values branch of HF LlamaAttention.forward
  * (modeling_llama.py:243-281) and the greedy step of generate (models/pointllm/model_arch.py:94-108,
