@@ -921,7 +921,10 @@ extern "C" int egomi_gemm_slab_count(const egomi_gemm_desc* d) {
 // split over blockIdx.y into fp32 slabs (caller-provided workspace) and combined.  -> number of K-slices (1 = no split)
 static int skinny_splitk(const egomi_gemm_desc* d, int nwg) {
     const int nt = d->K / FT_BK;
-    if (!(d->workspace && d->M <= 512 && nwg < 512)) return 1;
+    // ... and products of any height whose 128x128 tiles cover well under half the chip while K is long enough to cut
+    // (PointBERT fc2 at B = 8: 4104 x 384 x 1536 = 99 tiles x 24 K-steps)
+    const bool few_tiles = nwg <= 128 && nt >= 16 && d->epilogue == EGOMI_EPI_NONE;
+    if (!(d->workspace && (d->M <= 512 || few_tiles) && nwg < 512)) return 1;
     // measured (tools/gemm_bench_decode.py, M=256): ~256 blocks, and no more than ~32 K-steps per slice
     int sk = d->split_k > 0 ? d->split_k : (nwg >= 256 ? 1 : (256 + nwg - 1) / nwg);
     if (d->split_k <= 0 && sk > 1 && nt / sk > 32) sk *= 2;
