@@ -894,6 +894,9 @@ static int tile_choice(const egomi_gemm_desc* d) {
     // enough tiles to occupy the chip at one block per CU and a K long enough to amortise its prologue/epilogue
     const long long t256 = (long long)((d->M + 255) / 256) * ((d->N + 255) / 256);
     if (t256 >= 128 && d->K >= 2048 && (long long)d->M * d->lda < (1ll << 31) && (long long)d->N * d->ldb < (1ll << 31)) return 8;
+    // many tiles make up for a shorter K (lm_head wgrad of the step: 32262 x 4096 x 1280 = 2032 tiles, fp32 out: 365 vs 474 us,
+    // tools/debug/lmhead_wgrad_probe.py)
+    if (t256 >= 512 && d->K >= 1024 && (long long)d->M * d->lda < (1ll << 31) && (long long)d->N * d->ldb < (1ll << 31)) return 8;
     // few tiles but a very long K (the lm_head dgrad of the training step: 1280 x 4096 x 32320 = 80 tiles): every tile row K-sliced
     // (plan_tail with rows = all) fills the chip — tools/debug/lmhead_dgrad_probe.py: 313 us (S = 6) vs 482 us on the 128x128 kernel
     if (t256 >= 32 && t256 < 128 && d->K >= 8192 && d->M > 512 && d->epilogue == EGOMI_EPI_NONE && d->workspace &&
