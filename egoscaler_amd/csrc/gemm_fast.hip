@@ -310,6 +310,23 @@ void gemm_nt_bf16_kernel(FastArgs g) {
 //   rows beyond M / N clamp on load, mask on store; DMAs past the last K-tile re-load the last tile into
 //   buffers nobody reads any more, which keeps the vmcnt arithmetic constant.
 // =================================================================================================
+#ifdef GEMM_STAMP
+// Timing stamps of the per-tile 8-phase kernel (debug builds only, -DGEMM_STAMP; tools/debug/gemm_stamp.py): wave 0 of every
+// block adds its s_memtime deltas per segment to g_gemm_stamp[].
+__device__ unsigned long long g_gemm_stamp[16];
+extern "C" int egomi_gemm_stamp_read(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_gemm_stamp), sizeof(g_gemm_stamp)); }
+extern "C" int egomi_gemm_stamp_reset() { unsigned long long z[16] = {0}; return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_stamp), z, sizeof(z)); }
+#define GSTAMP_DECL unsigned long long gs_prev = 0, gs_acc[6] = {0, 0, 0, 0, 0, 0};
+#define GSTAMP_NOW(var) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory"); __builtin_amdgcn_sched_barrier(0); }
+#define GSTAMP_START GSTAMP_NOW(gs_prev)
+#define GSTAMP(i) { unsigned long long gs_n; GSTAMP_NOW(gs_n) gs_acc[i] += gs_n - gs_prev; gs_prev = gs_n; }
+#define GSTAMP_FLUSH if (threadIdx.x == 0) { for (int i = 0; i < 6; ++i) atomicAdd(&g_gemm_stamp[i], gs_acc[i]); atomicAdd(&g_gemm_stamp[8], 1ull); }
+#else
+#define GSTAMP_DECL
+#define GSTAMP_START
+#define GSTAMP(i)
+#define GSTAMP_FLUSH
+#endif
 #define P8_HT (128 * 64)
 template <typename TC>
 __global__ __launch_bounds__(512, 2)
@@ -319,6 +336,8 @@ void gemm_nt_bf16_8phase_kernel(FastArgs g) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wr = wave >> 2, wc = wave & 3;
 
+    GSTAMP_DECL
+    GSTAMP_START
     // whole tiles first (XCD-aware strips over the first full_tm tile rows), then the K-slices of the tail rows: the
     // dispatcher hands blocks out in index order, so the short blocks fill the ragged last round
     int tm, tn, kz = 0, ksl = 1;
@@ -413,8 +432,10 @@ void gemm_nt_bf16_8phase_kernel(FastArgs g) {
         const bf16_t* pB1 = g.B + (long long)t1 * FT_BK;
         P8_PF(0, 2, pB0, offB[0]) P8_PF(0, 0, pA0, offA[0]) P8_PF(0, 3, pB0, offB[1]) P8_PF(0, 1, pA0, offA[1])
         P8_PF(1, 2, pB1, offB[0]) P8_PF(1, 0, pA1, offA[0]) P8_PF(1, 3, pB1, offB[1])
+        GSTAMP(0)                                                 // set-up + DMA issue
         asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         P8_BAR
+        GSTAMP(1)                                                 // first tile landed
     }
     if (wr == 1) { P8_BAR }                                       // second wave group runs one barrier behind
     int t = t_begin;
@@ -424,8 +445,10 @@ void gemm_nt_bf16_8phase_kernel(FastArgs g) {
     }
     if (t < nt) P8_TILE(0, t)
     if (wr == 0) { P8_BAR }
+    GSTAMP(2)                                                     // main loop
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // the tail's redundant DMAs drain before the block's LDS is released
     __builtin_amdgcn_s_barrier();                                 // ... for every wave (unconditional: the epilogue below re-uses the stages per wave)
+    GSTAMP(3)                                                     // drain
     const int row0 = g.full_tm * 256;
     const int mb = m0 + wr * 128, nb = n0 + wc * 64;
     if (ksl > 1 && g.tickets) {
@@ -533,6 +556,12 @@ void gemm_nt_bf16_8phase_kernel(FastArgs g) {
                 }
             }
         }
+        GSTAMP(4)                                                 // epilogue issued
+#ifdef GEMM_STAMP
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+        GSTAMP(5)                                                 // stores acknowledged
+        GSTAMP_FLUSH
         return;
     }
     gemm_epilogue<TC, 8>(g, acc, mb, nb, lane, ksl > 1 ? g.ws + (long long)kz * (g.M - row0) * g.N : nullptr, row0);
