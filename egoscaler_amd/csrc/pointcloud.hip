@@ -368,17 +368,21 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(const float* pts, int 
     float* lp = reinterpret_cast<float*>(smem + 2 * 16 * sizeof(unsigned long long));   // [N][3]
     const int b = blockIdx.x, tid = threadIdx.x;
     const float* P = pts + (long long)b * N * C;
-    float px[PPT], py[PPT], pz[PPT], dist[PPT];
+    // points of a thread in pairs: the distance update runs on packed fp32 (v_pk_add/mul_f32; this file is built with
+    // -ffp-contract=off, so every element sees misc.py:57's un-fused (dx*dx + dy*dy) + dz*dz), and the thread's arg-max is kept
+    // as (distance, index) with a strict compare in increasing index order — the lowest index wins ties, as in the 64-bit key
+    constexpr int PP = (PPT + 1) / 2;
+    f32x2 px[PP], py[PP], pz[PP], dist[PP];
 #pragma unroll
-    for (int s = 0; s < PPT; ++s) {
+    for (int s = 0; s < 2 * PP; ++s) {
         const int j = s * FPS_THREADS + tid;
-        if (j < N) {
-            px[s] = P[(long long)j * C]; py[s] = P[(long long)j * C + 1]; pz[s] = P[(long long)j * C + 2];
-            lp[3 * j] = px[s]; lp[3 * j + 1] = py[s]; lp[3 * j + 2] = pz[s];
-            dist[s] = 1e10f;                                               // misc.py:51
-        } else {
-            px[s] = py[s] = pz[s] = 0.f; dist[s] = -1.f;                   // padding: never selected
+        float x = 0.f, y = 0.f, z = 0.f, d0 = -1.f;                        // padding: never selected
+        if (s < PPT && j < N) {
+            x = P[(long long)j * C]; y = P[(long long)j * C + 1]; z = P[(long long)j * C + 2];
+            lp[3 * j] = x; lp[3 * j + 1] = y; lp[3 * j + 2] = z;
+            d0 = 1e10f;                                                    // misc.py:51
         }
+        px[s >> 1][s & 1] = x; py[s >> 1][s & 1] = y; pz[s >> 1][s & 1] = z; dist[s >> 1][s & 1] = d0;
     }
     __syncthreads();
     int far = start[b];
@@ -389,18 +393,23 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(const float* pts, int 
             float* oc = out_center + ((long long)b * G + i) * 3;
             oc[0] = cx; oc[1] = cy; oc[2] = cz;
         }
-        unsigned long long best = 0ull;
+        const f32x2 cxv = {cx, cx}, cyv = {cy, cy}, czv = {cz, cz};
+        float bd = -1.f;
+        unsigned bj = 0u;
 #pragma unroll
-        for (int s = 0; s < PPT; ++s) {
-            const float dx = px[s] - cx, dy = py[s] - cy, dz = pz[s] - cz;
-            const float d = (dx * dx + dy * dy) + dz * dz;                 // misc.py:57 (un-fused)
-            if (dist[s] >= 0.f) {
-                dist[s] = fminf(dist[s], d);                               // misc.py:58
-                const unsigned j = (unsigned)(s * FPS_THREADS + tid);
-                const unsigned long long key = ((unsigned long long)__float_as_uint(dist[s]) << 32) | (0xFFFFFFFFu - j);
-                best = key > best ? key : best;
+        for (int s = 0; s < PP; ++s) {
+            const f32x2 dx = px[s] - cxv, dy = py[s] - cyv, dz = pz[s] - czv;
+            const f32x2 d = (dx * dx + dy * dy) + dz * dz;                 // misc.py:57 (un-fused)
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const float nd = fminf(dist[s][e], d[e]);                  // misc.py:58; padding stays at -1 and never beats bd
+                dist[s][e] = nd;
+                const bool c = nd > bd;
+                bd = c ? nd : bd;
+                bj = c ? (unsigned)((2 * s + e) * FPS_THREADS + tid) : bj;
             }
         }
+        unsigned long long best = bd < 0.f ? 0ull : (((unsigned long long)__float_as_uint(bd) << 32) | (0xFFFFFFFFu - bj));
         best = wave_max_u64(best);
         unsigned long long* sl = slots + (i & 1) * 16;
         if ((tid & 63) == 0) sl[tid >> 6] = best;
