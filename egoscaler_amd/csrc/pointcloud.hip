@@ -483,27 +483,49 @@ __global__ __launch_bounds__(KNN_WAVES * 64) void knn_group_kernel(const float* 
             d[s] = INFINITY;
         }
     }
+    // Two-level arg-min: the lane's 128 candidates are kept as 8 groups of 16 with their minima (orderable distance, slot); a
+    // round takes the best of the 8 minima, the wave picks the winner by (distance, index), and only the winner's GROUP — a
+    // wave-uniform number, so a scalar branch with static register indices — is re-scanned after its candidate is struck out.
+    // (The first form re-scanned all 128 candidates of every lane in every round: 32 x 512 VALU instructions per centre.)
+    constexpr int KG = 16, KNG = KNN_CAND / KG;
+    unsigned gu[KNG];
+    int gsl[KNG];
+#pragma unroll
+    for (int g = 0; g < KNG; ++g) {
+        unsigned mu = 0xFFFFFFFFu;
+        int ms = g * KG;
+#pragma unroll
+        for (int s = g * KG; s < (g + 1) * KG; ++s) {
+            const unsigned u = f32_orderable(d[s]);
+            if (u < mu) { mu = u; ms = s; }
+        }
+        gu[g] = mu; gsl[g] = ms;
+    }
     int mine = 0;
-    int kill = -1;
     for (int r = 0; r < K; ++r) {
         unsigned bu = 0xFFFFFFFFu;
         int bs = 0;
 #pragma unroll
-        for (int s = 0; s < KNN_CAND; ++s) {
-            if (s == kill) d[s] = INFINITY;
-            const unsigned u = f32_orderable(d[s]);
-            if (u < bu) { bu = u; bs = s; }
-        }
-        unsigned long long key = ((unsigned long long)bu << 32) | (unsigned)(bs * 64 + lane);
+        for (int g = 0; g < KNG; ++g)
+            if (gu[g] < bu) { bu = gu[g]; bs = gsl[g]; }                  // increasing slot order, strict: the lowest index wins ties
+        const unsigned long long key = ((unsigned long long)bu << 32) | (unsigned)(bs * 64 + lane);
+        const unsigned long long kmin = ~wave_max_u64(~key);              // wave-uniform (distance, index) minimum
+        const int widx = (int)(kmin & 0xFFFFFFFFu);
+        const int kslot = widx >> 6, kgrp = __builtin_amdgcn_readfirstlane(kslot / KG);
+        const bool winner = (widx & 63) == lane;
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            unsigned lo = __shfl_xor((unsigned)(key & 0xFFFFFFFFu), o, 64);
-            unsigned hi = __shfl_xor((unsigned)(key >> 32), o, 64);
-            unsigned long long other = ((unsigned long long)hi << 32) | lo;
-            key = other < key ? other : key;
+        for (int g = 0; g < KNG; ++g) {
+            if (g != kgrp) continue;                                       // wave-uniform
+            unsigned mu = 0xFFFFFFFFu;
+            int ms = g * KG;
+#pragma unroll
+            for (int s = g * KG; s < (g + 1) * KG; ++s) {
+                if (winner && s == kslot) d[s] = INFINITY;
+                const unsigned u = f32_orderable(d[s]);
+                if (u < mu) { mu = u; ms = s; }
+            }
+            gu[g] = mu; gsl[g] = ms;
         }
-        const int widx = (int)(key & 0xFFFFFFFFu);
-        kill = ((widx & 63) == lane) ? (widx >> 6) : -1;
         if (lane == r) mine = widx;
     }
     if (lane < K) out_idx[(long long)gidx * K + lane] = mine;            // ordered by (distance, index)
