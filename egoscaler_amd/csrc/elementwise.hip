@@ -82,10 +82,71 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const T* x, const T* w
     }
 }
 
+// rmsnorm_fwd_kernel for an input whose last rows are still K-slice slabs of the producing GEMM (EGOMI_EPI_SLABS on a large
+// product, include/egomi.h): rows >= row0 are first formed as x = round(sum_s slab[s] (+ residual)) — what the combine pass would
+// have stored — written to x, and normalised from registers; rows < row0 take rmsnorm_fwd_kernel's path.  Same arithmetic and
+// summation order as the two separate kernels.
+template <typename T, int MAXV>
+__global__ __launch_bounds__(256) void rmsnorm_fwd_tail_kernel(T* x, const T* w, T* y, float* rstd_out, int cols, float eps, int row0, const float* slabs,
+                                                               int sk, long long slab_stride, const T* residual, long long ldr) {
+    __shared__ float red[16];
+    const long long row = blockIdx.x;
+    float xv[MAXV][8];
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = (threadIdx.x + i * 256) * 8;
+        if (c < cols) {
+            if (row >= row0) {                                           // block-uniform
+                float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                for (int s2 = 0; s2 < sk; ++s2) {
+                    float t[8];
+                    load8<float>(slabs + (long long)s2 * slab_stride + (row - row0) * cols + c, t);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] += t[j];
+                }
+                if (residual) {
+                    float r[8];
+                    load8<T>(residual + row * ldr + c, r);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] += r[j];
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) xv[i][j] = sizeof(T) == 2 ? bf2f(f2bf(v[j])) : v[j];
+                store8<T>(x + row * cols + c, xv[i]);
+            } else {
+                load8<T>(x + row * cols + c, xv[i]);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) ss += xv[i][j] * xv[i][j];
+        }
+    }
+    const float rstd = rsqrtf(block_sum(ss, red) / cols + eps);
+    if (rstd_out && threadIdx.x == 0) rstd_out[row] = rstd;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = (threadIdx.x + i * 256) * 8;
+        if (c < cols) {
+            float ww[8], o[8];
+            load8<T>(w + c, ww);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float h = xv[i][j] * rstd;
+                if (sizeof(T) == 2) h = bf2f(f2bf(h));      // .to(input_dtype) before the weight multiply
+                o[j] = ww[j] * h;
+            }
+            store8<T>(y + row * cols + c, o);
+        }
+    }
+}
+
 // dx = rstd * (g - x_hat * mean(g * x_hat)),  g = w * dy;  dw[c] += sum_rows dy * x_hat.
 // one row per block (grid-stride kept for generality); the weight gradient is rmsnorm_dw_kernel's job.
+// Tail form (row0 < rows): dy rows >= row0 are still K-slice slabs of the dgrad GEMM that produced dy (EGOMI_EPI_SLABS): they are
+// summed and rounded here — and written back to dy, which the weight-gradient pass reads — instead of in a combine pass.
 template <typename T, int MAXV>
-__global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const T* dy, const T* x, const T* w, const float* rstd, T* dx, const T* dx_add, int rows, int cols) {
+__global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(T* dy, const T* x, const T* w, const float* rstd, T* dx, const T* dx_add, int rows, int cols,
+                                                          int row0, const float* slabs, int sk, long long slab_stride) {
     __shared__ float red[16];
     // MAXV = ceil(cols / 2048) chunks of 8 columns per thread (cols <= 8192)
     for (long long row = blockIdx.x; row < rows; row += gridDim.x) {
@@ -97,7 +158,23 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const T* dy, const T* 
             const int c = (threadIdx.x + i * 256) * 8;
             if (c < cols) {
                 float g[8], xv[8], ww[8];
-                load8<T>(dy + row * cols + c, g);
+                if (row >= row0) {                                       // block-uniform
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) g[j] = 0.f;
+                    for (int s2 = 0; s2 < sk; ++s2) {
+                        float t[8];
+                        load8<float>(slabs + (long long)s2 * slab_stride + (row - row0) * cols + c, t);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) g[j] += t[j];
+                    }
+                    if (sizeof(T) == 2) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) g[j] = bf2f(f2bf(g[j]));
+                    }
+                    store8<T>(dy + row * cols + c, g);
+                } else {
+                    load8<T>(dy + row * cols + c, g);
+                }
                 load8<T>(x + row * cols + c, xv);
                 load8<T>(w + c, ww);
                 if (dx_add) load8<T>(dx_add + row * cols + c, ad[i]);
@@ -163,29 +240,54 @@ extern "C" int egomi_rmsnorm_fwd(const void* x, const void* w, void* y, float* r
     return egomi_launch_status();
 }
 
-extern "C" int egomi_rmsnorm_bwd(const void* dy, const void* x, const void* w, const float* rstd, void* dx, const void* dx_add,
-                                 float* dw, int rows, int cols, int dtype, egomi_stream_t stream) {
+static int rmsnorm_bwd_impl(void* dy, const void* x, const void* w, const float* rstd, void* dx, const void* dx_add, float* dw, int rows, int cols,
+                            int row0, const float* slabs, int sk, int dtype, egomi_stream_t stream) {
     if (!dy || !x || !w || !rstd || !dx) return EGOMI_E_BADARG;
     if (rows <= 0 || cols <= 0 || cols % 8) return EGOMI_E_SHAPE;
     if (cols > 8192) return EGOMI_E_UNSUPPORTED;
-    // one row per block keeps every CU's memory pipe full; the weight gradient, when wanted, is its own pass (above)
-    const int grid = rows;
-    if (dw) {
+    const bool tail = row0 < rows;
+    const long long stride = (long long)(rows - row0) * cols;
+    // one row per block keeps every CU's memory pipe full; the weight gradient, when wanted, is its own pass (above).  With a
+    // tail the row kernel runs FIRST: it is the one that materialises dy's last rows, which the weight-gradient pass reads.
+    auto dw_pass = [&]() {
         const int rseg = rows >= 2048 ? 8 : (rows >= 256 ? 2 : 1);
         EGOMI_DISPATCH_DTYPE(dtype, EGOMI_LAUNCH(rmsnorm_dw_kernel<T>, dim3((cols + 63) / 64, rseg), dim3(256), 0, (hipStream_t)stream,
                                                        (const T*)dy, (const T*)x, rstd, dw, rows, cols));
-        dw = nullptr;                                                   // the row kernel below only produces dx
-    }
-    if (cols <= 2048) {
-        EGOMI_DISPATCH_DTYPE(dtype, EGOMI_LAUNCH((rmsnorm_bwd_kernel<T, 1>), dim3(grid), dim3(256), 0, (hipStream_t)stream,
-                                                       (const T*)dy, (const T*)x, (const T*)w, rstd, (T*)dx, (const T*)dx_add, rows, cols));
-    } else if (cols <= 4096) {
-        EGOMI_DISPATCH_DTYPE(dtype, EGOMI_LAUNCH((rmsnorm_bwd_kernel<T, 2>), dim3(grid), dim3(256), 0, (hipStream_t)stream,
-                                                       (const T*)dy, (const T*)x, (const T*)w, rstd, (T*)dx, (const T*)dx_add, rows, cols));
-    } else {
-        EGOMI_DISPATCH_DTYPE(dtype, EGOMI_LAUNCH((rmsnorm_bwd_kernel<T, 4>), dim3(grid), dim3(256), 0, (hipStream_t)stream,
-                                                       (const T*)dy, (const T*)x, (const T*)w, rstd, (T*)dx, (const T*)dx_add, rows, cols));
-    }
+        return 0;
+    };
+    if (dw && !tail) dw_pass();
+    const int grid = rows;
+#define RNB(V) EGOMI_DISPATCH_DTYPE(dtype, EGOMI_LAUNCH((rmsnorm_bwd_kernel<T, V>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (T*)dy, (const T*)x, \
+                                                        (const T*)w, rstd, (T*)dx, (const T*)dx_add, rows, cols, row0, slabs, sk, stride))
+    if (cols <= 2048) RNB(1); else if (cols <= 4096) RNB(2); else RNB(4);
+#undef RNB
+    if (dw && tail) dw_pass();
+    return egomi_launch_status();
+}
+
+extern "C" int egomi_rmsnorm_bwd(const void* dy, const void* x, const void* w, const float* rstd, void* dx, const void* dx_add,
+                                 float* dw, int rows, int cols, int dtype, egomi_stream_t stream) {
+    return rmsnorm_bwd_impl(const_cast<void*>(dy), x, w, rstd, dx, dx_add, dw, rows, cols, rows, nullptr, 0, dtype, stream);
+}
+
+// the *_tail forms: the last rows of the input are still the K-slice slabs of the GEMM that produced it (include/egomi.h)
+extern "C" int egomi_rmsnorm_bwd_tail(void* dy, const void* x, const void* w, const float* rstd, void* dx, const void* dx_add, float* dw, int rows,
+                                      int cols, int row0, const float* slabs, int slices, int dtype, egomi_stream_t stream) {
+    if (row0 < 0 || row0 > rows || (row0 < rows && (!slabs || slices < 1 || ((uintptr_t)slabs & 15)))) return EGOMI_E_SHAPE;
+    return rmsnorm_bwd_impl(dy, x, w, rstd, dx, dx_add, dw, rows, cols, row0, slabs, slices, dtype, stream);
+}
+
+extern "C" int egomi_rmsnorm_fwd_tail(void* x, const void* w, void* y, float* rstd, int rows, int cols, float eps, int row0, const float* slabs, int slices,
+                                      const void* residual, int64_t ldr, int dtype, egomi_stream_t stream) {
+    if (!x || !w || !y) return EGOMI_E_BADARG;
+    if (rows <= 0 || cols <= 0 || cols % 8 || row0 < 0 || row0 > rows) return EGOMI_E_SHAPE;
+    if (row0 < rows && (!slabs || slices < 1 || ((uintptr_t)slabs & 15) || (residual && (ldr < cols || ldr % 8)))) return EGOMI_E_SHAPE;
+    if (cols > 8192) return EGOMI_E_UNSUPPORTED;
+    const long long stride = (long long)(rows - row0) * cols;
+#define RNF(V) EGOMI_DISPATCH_DTYPE(dtype, EGOMI_LAUNCH((rmsnorm_fwd_tail_kernel<T, V>), dim3(rows), dim3(256), 0, (hipStream_t)stream, (T*)x, (const T*)w, (T*)y, \
+                                                        rstd, cols, eps, row0, slabs, slices, stride, (const T*)residual, (long long)ldr))
+    if (cols <= 2048) RNF(1); else if (cols <= 4096) RNF(2); else RNF(4);
+#undef RNF
     return egomi_launch_status();
 }
 

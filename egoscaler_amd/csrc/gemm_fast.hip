@@ -1092,25 +1092,49 @@ static int launch_p8(const egomi_gemm_desc* d, FastArgs& g, const P8Sched& sc, h
     return egomi_launch_status();
 }
 
-static int launch_8phase(const egomi_gemm_desc* d, FastArgs& g, hipStream_t s, int* tickets = nullptr, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr) {
-    g.tiles_m = (d->M + 255) / 256; g.tiles_n = (d->N + 255) / 256;
-    g.splitk = 1; g.ws = (float*)d->workspace;
+// the tail plan launch_8phase will run for this descriptor (d->workspace already points at the slab area)
+static TailPlan tail_plan_for(const egomi_gemm_desc* d) {
+    const int tiles_m = (d->M + 255) / 256;
     static int no_tail = -1;
     if (no_tail < 0) { const char* e = getenv("EGOMI_GEMM_NO_TAIL"); no_tail = e ? atoi(e) : 0; }
     TailPlan tp = {0, 1};
     if (d->workspace && !no_tail) tp = plan_tail(d->M, d->N, d->K, d->workspace_bytes);
     if (d->split_k > 0 && d->workspace) {                             // explicit override (experiments): split_k = rows * 16 + S
         tp.rows = d->split_k / 16; tp.s = d->split_k % 16;
-        if (tp.rows > g.tiles_m) tp.rows = g.tiles_m;
+        if (tp.rows > tiles_m) tp.rows = tiles_m;
         if (tp.s < 2 || tp.rows < 1) tp = {0, 1};
     }
     if (tp.rows) {                                                    // slabs must fit the caller's scratch, slices must be non-empty
-        const long long rows_rel = d->M - (long long)(g.tiles_m - tp.rows) * 256;
+        const long long rows_rel = d->M - (long long)(tiles_m - tp.rows) * 256;
         const int nt = d->K / FT_BK;
         if (tp.s > nt) tp.s = nt;
         if (tp.s > 1) { const int per = (nt + tp.s - 1) / tp.s; tp.s = (nt + per - 1) / per; }
         if (tp.s < 2 || rows_rel * d->N * 4 * tp.s > d->workspace_bytes) tp = {0, 1};
     }
+    return tp;
+}
+
+// EGOMI_EPI_SLABS on a product that takes the 256x256 kernel: rows >= *row0 are left as *slices fp32 slabs [slices][M - row0][N]
+// at the start of the slab area (workspace + 4096 when ws_tickets_zeroed); *slices = 0: every row gets the normal epilogue
+extern "C" int egomi_gemm_tail_plan(const egomi_gemm_desc* d0, int* row0, int* slices) {
+    if (!d0 || !row0 || !slices) return EGOMI_E_BADARG;
+    *row0 = d0->M; *slices = 0;
+    if (d0->force_generic || !fast_applicable(d0) || tile_choice(d0) != 8) return EGOMI_E_UNSUPPORTED;
+    egomi_gemm_desc dl = *d0;
+    if (dl.ws_tickets_zeroed && dl.workspace) {
+        if (dl.workspace_bytes > 4096) { dl.workspace = (char*)dl.workspace + 4096; dl.workspace_bytes -= 4096; }
+        else { dl.workspace = nullptr; dl.workspace_bytes = 0; }
+    }
+    const TailPlan tp = tail_plan_for(&dl);
+    if (tp.rows) { *row0 = ((dl.M + 255) / 256 - tp.rows) * 256; *slices = tp.s; }
+    return EGOMI_OK;
+}
+
+static int launch_8phase(const egomi_gemm_desc* d, FastArgs& g, hipStream_t s, int* tickets = nullptr, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr,
+                         bool leave_slabs = false) {
+    g.tiles_m = (d->M + 255) / 256; g.tiles_n = (d->N + 255) / 256;
+    g.splitk = 1; g.ws = (float*)d->workspace;
+    const TailPlan tp = tail_plan_for(d);
     g.full_tm = g.tiles_m - tp.rows; g.tail_s = tp.s; g.full_tiles = g.full_tm * g.tiles_n;
     // in-launch combine: needs the caller's ticket words (4 KB ahead of the slabs, include/egomi.h `ws_tickets_zeroed`) and room for
     // whole 256x256 slabs of every tail tile and slice
@@ -1123,6 +1147,7 @@ static int launch_8phase(const egomi_gemm_desc* d, FastArgs& g, hipStream_t s, i
     else EGOMI_LAUNCH(gemm_nt_bf16_8phase_kernel<float>, dim3(nwg, 1), dim3(512), 0, s, g);
     if (t1) (void)hipEventRecord(t1, s);
     if (tp.rows && g.epi == 1 && g.tickets) g.tickets = nullptr;         // the fused SwiGLU epilogue wants the separate combine + tail pass below
+    if (leave_slabs) return egomi_launch_status();                       // EGOMI_EPI_SLABS: the caller's next kernel sums the tail rows' slabs
     if (tp.rows && !g.tickets) {
         FastArgs r = g;
         const long long row0 = (long long)g.full_tm * 256;
@@ -1162,6 +1187,18 @@ int egomi_gemm_fast_try(const egomi_gemm_desc* d0, hipStream_t s) {
     g.alpha = d->alpha; g.accumulate = d->accumulate; g.act = d->act; g.tickets = nullptr;
     g.epi = d->epilogue; g.C2 = d->C2; g.ldc2 = d->ldc2;
     const int tc = tile_choice(d);
+    if (d->epilogue == EGOMI_EPI_SLABS && tc == 8) {
+        // large products: only the K-sliced TAIL rows are left as slabs (egomi_gemm_tail_plan tells which); whole tiles get the
+        // normal epilogue, residual included
+        if (d->bias || d->accumulate || d->act != 0 || d->alpha != 1.0f || d->c_dtype != EGOMI_BF16 || (d->N & 7) ||
+            (long long)d->M * d->lda >= (1ll << 31) || (long long)d->N * d->ldb >= (1ll << 31)) return EGOMI_E_UNSUPPORTED;
+        if (dl.ws_tickets_zeroed && dl.workspace) {
+            if (dl.workspace_bytes > 4096) { dl.workspace = (char*)dl.workspace + 4096; dl.workspace_bytes -= 4096; }
+            else { dl.workspace = nullptr; dl.workspace_bytes = 0; }
+        }
+        g.epi = 0;
+        return launch_8phase(d, g, s, nullptr, t0, t1, true);
+    }
     if (d->epilogue == EGOMI_EPI_SLABS) {
         if (!slabs_form_ok(d) || tc != 1) return EGOMI_E_UNSUPPORTED;
         if (dl.ws_tickets_zeroed && dl.workspace) {                     // same scratch convention as below: slabs start behind the ticket words

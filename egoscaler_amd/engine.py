@@ -60,6 +60,7 @@ class Engine:
         self.use_fused_attention = True
         self.use_fused_swiglu = os.environ.get("EGOMI_NO_FUSED_SWIGLU", "0") != "1"   # SwiGLU in the gate|up GEMM epilogue where the 256x256
                                                                                       # kernel runs (tests and A/B runs switch it off)
+        self.use_tail_fuse = os.environ.get("EGOMI_NO_TAIL_FUSE", "0") != "1"         # K-sliced tail rows summed by the RMSNorm that reads them
         self.pb_trainer = None
         self.pb_train_mode = False          # set by TrajPointLLMForCausalLM.train(): point backbone in train() mode
         self.prepared_bn_stale = False
@@ -350,6 +351,10 @@ class Engine:
             key_mask = attention_mask.to(device=self.device, dtype=torch.uint8).contiguous()
         scale = hd ** -0.5
         fused = self.use_fused_attention and T == torch.bfloat16 and hd == 128
+        # the K-sliced tail rows of o_proj / down_proj (and, in backward, of the qkv / gate|up dgrads) are summed by the RMSNorm
+        # kernel that reads them instead of by a combine pass (EGOMI_EPI_SLABS, include/egomi.h).  EGOMI_NO_TAIL_FUSE=1: A/B switch
+        defer = self.use_tail_fuse and T == torch.bfloat16
+        pend = pend_res = None
         fuse_swiglu = self.use_fused_swiglu and T == torch.bfloat16 and self.gu_il and (2 * Fd) % 256 == 0 and ops.gemm_kernel_id(M, 2 * Fd, d) == 2
         for l in range(L):
             p = f"model.layers.{l}."
@@ -370,7 +375,8 @@ class Engine:
                 h, ao, h2, act = ws.get("h", (M, d), T), ws.get("ao", (M, d), T), ws.get("h2", (M, d), T), ws.get("act", (M, Fd), T)
                 x_mid, x_out = ws.get("x_mid", (M, d), T), ws.get(f"x_out{l & 1}", (M, d), T)
                 qkv, gu, rstd1, rstd2 = ws.get("qkv", (M, 3 * d), T), ws.get("gu", (M, 2 * Fd), T), None, None
-            ops.rmsnorm(x, w[p + "input_layernorm.weight"], lm.rms_norm_eps, rstd=rstd1, out=h)
+            ops.rmsnorm(x, w[p + "input_layernorm.weight"], lm.rms_norm_eps, rstd=rstd1, out=h, tail=pend, tail_residual=pend_res)
+            pend = pend_res = None
             if l in self.wqkv:
                 ops.mm(h, self.wqkv[l], out=qkv)
             else:
@@ -388,8 +394,12 @@ class Engine:
                 ops.attn_fwd(qkv, B, S, H, hd, scale, ao, lse, causal=True, key_mask=key_mask)
             else:
                 Pm = self._attention(qkv, B, S, H, hd, ao, True, key_mask, scale, save)
-            ops.mm(ao, w[p + "self_attn.o_proj.weight"], out=x_mid, residual=x)
-            ops.rmsnorm(x_mid, w[p + "post_attention_layernorm.weight"], lm.rms_norm_eps, rstd=rstd2, out=h2)
+            if defer:                                          # the K-sliced tail rows of the product are summed by the norm that reads them
+                _, t_o = ops.mm(ao, w[p + "self_attn.o_proj.weight"], out=x_mid, residual=x, defer_tail=True)
+                ops.rmsnorm(x_mid, w[p + "post_attention_layernorm.weight"], lm.rms_norm_eps, rstd=rstd2, out=h2, tail=t_o, tail_residual=x)
+            else:
+                ops.mm(ao, w[p + "self_attn.o_proj.weight"], out=x_mid, residual=x)
+                ops.rmsnorm(x_mid, w[p + "post_attention_layernorm.weight"], lm.rms_norm_eps, rstd=rstd2, out=h2)
             if l in self.wgu and self.gu_il:
                 if fuse_swiglu:
                     ops.mm(h2, self.wgu[l], out=gu, swiglu_out=act)          # act leaves the GEMM epilogue; gu (interleaved-32) is kept for backward
@@ -403,14 +413,18 @@ class Engine:
                     ops.mm(h2, w[p + "mlp.gate_proj.weight"], out=gu[:, :Fd])
                     ops.mm(h2, w[p + "mlp.up_proj.weight"], out=gu[:, Fd:])
                 ops.swiglu(gu[:, :Fd], gu[:, Fd:], act)
-            ops.mm(act, w[p + "mlp.down_proj.weight"], out=x_out, residual=x_mid)
+            if defer:                                          # ... here by the NEXT layer's input norm (or the final norm)
+                _, pend = ops.mm(act, w[p + "mlp.down_proj.weight"], out=x_out, residual=x_mid, defer_tail=True)
+                pend_res = x_mid
+            else:
+                ops.mm(act, w[p + "mlp.down_proj.weight"], out=x_out, residual=x_mid)
             if save:
                 lc.update(P=Pm, lse=lse, x_mid=x_mid, h=h, ao=ao, h2=h2, act=act)
                 ctx["layers"].append(lc)
             x = x_out
         rstd_f = torch.empty(M, dtype=torch.float32, device=self.device) if save else None
         hn = torch.empty(M, d, dtype=T, device=self.device)
-        ops.rmsnorm(x, w["model.norm.weight"], lm.rms_norm_eps, rstd=rstd_f, out=hn)
+        ops.rmsnorm(x, w["model.norm.weight"], lm.rms_norm_eps, rstd=rstd_f, out=hn, tail=pend, tail_residual=pend_res)
         if save:
             ctx.update(x_last=x, rstd_f=rstd_f, hn=hn, key_mask=key_mask)
             self.ctx = ctx
@@ -515,6 +529,8 @@ class Engine:
         tr = self.trainable
         dw = self.grad_buffer("model.norm.weight") if "model.norm.weight" in tr else None
         dx = ops.rmsnorm_bwd(d_hn, ctx["x_last"], w["model.norm.weight"], ctx["rstd_f"], dw=dw, out=ws.get("dx_a", (M, d), T))
+        # frozen layers only: with trainable layers the wgrad products between a dgrad and its norm would reuse the slab area
+        defer_b = self.use_tail_fuse and T == torch.bfloat16 and not self.any_layer_trainable
         for l in reversed(range(L)):
             p = f"model.layers.{l}."
             lc = ctx["layers"][l]
@@ -527,8 +543,12 @@ class Engine:
                 ops.swiglu_il_bwd(d_act, gu, dgu)                               # gu / dgu in the interleaved-32 layout of the stacked weight
             else:
                 ops.swiglu_bwd(d_act, gu[:, :Fd], gu[:, Fd:], dgu[:, :Fd], dgu[:, Fd:])
+            t_h2 = None
             if self.prepared and l in self.wguT:
-                d_h2 = ops.mm(dgu, self.wguT[l], out=ws.get("d_h", (M, d), T))
+                if defer_b:
+                    d_h2, t_h2 = ops.mm(dgu, self.wguT[l], out=ws.get("d_h", (M, d), T), defer_tail=True)
+                else:
+                    d_h2 = ops.mm(dgu, self.wguT[l], out=ws.get("d_h", (M, d), T))
             else:
                 d_h2 = self._dgrad(dgu[:, :Fd], p + "mlp.gate_proj.weight", ws.get("d_h", (M, d), T))
                 self._dgrad(dgu[:, Fd:], p + "mlp.up_proj.weight", d_h2, residual=d_h2)
@@ -536,7 +556,7 @@ class Engine:
             self._wgrad(p + "mlp.up_proj.weight", dgu[:, Fd:], lc["h2"])
             n2 = p + "post_attention_layernorm.weight"
             d_mid = ops.rmsnorm_bwd(d_h2, lc["x_mid"], w[n2], lc["rstd2"], dx_add=dx,
-                                    dw=self.grad_buffer(n2) if n2 in tr else None, out=ws.get("dx_b", (M, d), T))
+                                    dw=self.grad_buffer(n2) if n2 in tr else None, out=ws.get("dx_b", (M, d), T), tail=t_h2)
             # ---- attention
             d_ao = self._dgrad(d_mid, p + "self_attn.o_proj.weight", ws.get("d_ao", (M, d), T))
             self._wgrad(p + "self_attn.o_proj.weight", d_mid, lc["ao"])
@@ -548,8 +568,12 @@ class Engine:
             else:
                 self._attention_bwd(qkv, lc["P"], d_ao, dqkv, B, S, H, hd, scale)
                 ops.rope_(dqkv, self.cos, self.sin, M, S, 0, 2 * H, hd, 3 * d, inverse=True)
+            t_h = None
             if self.prepared and l in self.wqkvT:
-                d_h = ops.mm(dqkv, self.wqkvT[l], out=ws.get("d_h", (M, d), T))
+                if defer_b:
+                    d_h, t_h = ops.mm(dqkv, self.wqkvT[l], out=ws.get("d_h", (M, d), T), defer_tail=True)
+                else:
+                    d_h = ops.mm(dqkv, self.wqkvT[l], out=ws.get("d_h", (M, d), T))
             else:
                 d_h = self._dgrad(dqkv[:, :d], p + "self_attn.q_proj.weight", ws.get("d_h", (M, d), T))
                 self._dgrad(dqkv[:, d:2 * d], p + "self_attn.k_proj.weight", d_h, residual=d_h)
@@ -558,7 +582,7 @@ class Engine:
                 self._wgrad(p + f"self_attn.{nm}_proj.weight", dqkv[:, i * d:(i + 1) * d], lc["h"])
             n1 = p + "input_layernorm.weight"
             dx = ops.rmsnorm_bwd(d_h, lc["x_in"], w[n1], lc["rstd1"], dx_add=d_mid,
-                                 dw=self.grad_buffer(n1) if n1 in tr else None, out=ws.get("dx_a", (M, d), T))
+                                 dw=self.grad_buffer(n1) if n1 in tr else None, out=ws.get("dx_a", (M, d), T), tail=t_h)
             self._notify_layer(l)
         # ---- embedding + splice + projector (pointllm.py:107,126-129,155)
         Pn = pb.point_token_len

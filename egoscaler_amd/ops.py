@@ -192,7 +192,7 @@ def _tail_workspace(device, nbytes=(4096 + 256 * 2 * 262144)):
 
 def gemm_raw(A, B, C, M, N, K, lda, ldb, ldc, a_layout=0, b_layout=0, bias=None, residual=None, ldr=0,
              act=0, alpha=1.0, accumulate=False, batch=1, batch_inner=1, strides=(0, 0, 0, 0, 0, 0), force_generic=False,
-             workspace=None, split_k=0, persistent=None, swiglu_out=None, slabs=False, count_only=False):
+             workspace=None, split_k=0, persistent=None, swiglu_out=None, slabs=False, count_only=False, defer_tail=False):
     """C = act(alpha*A.B + bias) + residual (+C).  A/B/C are tensors whose data_ptr() is the first
     element of the (first) operand; all strides in elements.  See include/egomi.h."""
     if A.dtype != B.dtype:
@@ -234,6 +234,15 @@ def gemm_raw(A, B, C, M, N, K, lda, ldb, ldc, a_layout=0, b_layout=0, bias=None,
             raise _lib.EgomiError("gemm: the library would not split this product (egomi_gemm_slab_count == 0)")
         call("egomi_gemm", ctypes.byref(d), S())
         return n
+    tail = None
+    if defer_tail and d.workspace and bias is None and act == 0 and alpha == 1.0 and not accumulate and swiglu_out is None and \
+            C.dtype == torch.bfloat16:
+        # EGOMI_EPI_SLABS on a large product: the K-sliced tail rows stay as fp32 slabs for the caller's next kernel (ops.rmsnorm /
+        # ops.rmsnorm_bwd with tail=...); nothing changes when the library's plan has no such rows for this shape
+        row0, slices = c_i(0), c_i(0)
+        if _lib.lib().egomi_gemm_tail_plan(ctypes.byref(d), ctypes.byref(row0), ctypes.byref(slices)) == 0 and slices.value >= 2:
+            d.epilogue = 2
+            tail = (row0.value, slices.value, d.workspace + (4096 if d.ws_tickets_zeroed else 0))
     prof = PROFILER
     flops = 2.0 * M * N * K * max(1, batch)
     kid = _lib.lib().egomi_gemm_kernel_id(ctypes.byref(d)) if (prof is not None and prof.enabled and flops >= prof.min_flops) else None
@@ -252,7 +261,7 @@ def gemm_raw(A, B, C, M, N, K, lda, ldb, ldc, a_layout=0, b_layout=0, bias=None,
         prof.recs.append((e0, e1, flops, k0, k1))
     else:
         call("egomi_gemm", ctypes.byref(d), S())
-    return C
+    return (C, tail) if defer_tail else C
 
 
 def _ld(t):
@@ -305,16 +314,27 @@ def layernorm(x, w, b, eps=1e-5, add=None, sum_out=None, out=None):
     return out
 
 
-def rmsnorm(x, w, eps, rstd=None, out=None):
+def rmsnorm(x, w, eps, rstd=None, out=None, tail=None, tail_residual=None):
+    """tail = (row0, slices, slab address) from mm(..., defer_tail=True): rows >= row0 of x are formed here from the product's
+    K-slice slabs (+ tail_residual's rows), written to x and normalised in one pass (egomi_rmsnorm_fwd_tail)."""
     rows, cols = x.numel() // x.shape[-1], x.shape[-1]
     out = torch.empty_like(x) if out is None else out
+    if tail is not None:
+        call("egomi_rmsnorm_fwd_tail", P(x), P(w), P(out), P(rstd), c_i(rows), c_i(cols), c_f(eps), c_i(tail[0]), c_p(tail[2]), c_i(tail[1]),
+             P(tail_residual), c_i64(_ld(tail_residual) if tail_residual is not None else 0), c_i(dt(x.dtype)), S())
+        return out
     call("egomi_rmsnorm_fwd", P(x), P(w), P(out), P(rstd), c_i(rows), c_i(cols), c_f(eps), c_i(dt(x.dtype)), S())
     return out
 
 
-def rmsnorm_bwd(dy, x, w, rstd, dx_add=None, dw=None, out=None):
+def rmsnorm_bwd(dy, x, w, rstd, dx_add=None, dw=None, out=None, tail=None):
+    """tail: as in rmsnorm() — dy's rows >= row0 are still the slabs of the dgrad product that made dy (egomi_rmsnorm_bwd_tail)."""
     rows, cols = x.numel() // x.shape[-1], x.shape[-1]
     out = torch.empty_like(x) if out is None else out
+    if tail is not None:
+        call("egomi_rmsnorm_bwd_tail", P(dy), P(x), P(w), P(rstd), P(out), P(dx_add), P(dw), c_i(rows), c_i(cols), c_i(tail[0]), c_p(tail[2]), c_i(tail[1]),
+             c_i(dt(x.dtype)), S())
+        return out
     call("egomi_rmsnorm_bwd", P(dy), P(x), P(w), P(rstd), P(out), P(dx_add), P(dw), c_i(rows), c_i(cols), c_i(dt(x.dtype)), S())
     return out
 

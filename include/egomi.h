@@ -160,6 +160,11 @@ int egomi_gemm(const egomi_gemm_desc* desc, egomi_stream_t stream);
  * NT kernel, 0 = generic */
 int egomi_gemm_kernel_id(const egomi_gemm_desc* desc);
 int egomi_gemm_slab_count(const egomi_gemm_desc* desc);   /* EGOMI_EPI_SLABS: slices egomi_gemm will leave for this descriptor, 0 = none */
+/* EGOMI_EPI_SLABS on a LARGE product (egomi_gemm_kernel_id == 2): whole 256-row tiles get the normal epilogue (residual
+ * included); the K-sliced tail rows [row0, M) are left as `slices` fp32 slabs [slices][M - row0][N] at the start of the slab
+ * area (workspace + 4096 when ws_tickets_zeroed) for egomi_rmsnorm_fwd_tail / egomi_rmsnorm_bwd_tail to sum.  bf16 output, no
+ * bias / activation / alpha / accumulate.  slices = 0: the plan has no tail rows, nothing is pending. */
+int egomi_gemm_tail_plan(const egomi_gemm_desc* desc, int* row0, int* slices);
 /* Measurement hooks (bench.py `roofline`; no reference counterpart).  egomi_gemm_time_next(start, stop): the NEXT egomi_gemm call
  * of this thread, if it takes the 256x256 kernel (egomi_gemm_kernel_id == 2), records `start` right before and `stop` right after
  * THAT kernel on the launch stream — the slab-combine pass of K-sliced tail rows is a separate kernel and lies outside the
@@ -291,6 +296,14 @@ int egomi_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd, int ro
                       egomi_stream_t stream);
 int egomi_rmsnorm_bwd(const void* dy, const void* x, const void* w, const float* rstd, void* dx, const void* dx_add,
                       float* dw, int rows, int cols, int dtype, egomi_stream_t stream);
+/* Tail forms: rows >= row0 of the input (x resp. dy) are still the `slices` fp32 K-slice slabs [slices][rows - row0][cols] an
+ * EGOMI_EPI_SLABS product left (egomi_gemm_tail_plan); they are summed in slice order (+ residual rows for the forward form),
+ * rounded, WRITTEN to x / dy, and normalised in the same pass — bit-identical to the combine pass followed by
+ * egomi_rmsnorm_fwd / egomi_rmsnorm_bwd.  row0 == rows: no pending rows (then exactly the plain kernels' arithmetic). */
+int egomi_rmsnorm_fwd_tail(void* x, const void* w, void* y, float* rstd, int rows, int cols, float eps, int row0, const float* slabs, int slices,
+                           const void* residual, int64_t ldr, int dtype, egomi_stream_t stream);
+int egomi_rmsnorm_bwd_tail(void* dy, const void* x, const void* w, const float* rstd, void* dx, const void* dx_add, float* dw, int rows,
+                           int cols, int row0, const float* slabs, int slices, int dtype, egomi_stream_t stream);
 
 /* RoPE in place on x [rows, H, hd] (row stride ld elements); position of row r = pos_offset + r % S;
  * cos/sin tables fp32 [>= pos_offset+S, hd/2].  inverse=1 applies the transposed rotation (backward).

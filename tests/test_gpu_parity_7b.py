@@ -163,3 +163,32 @@ def test_bf16_7b_width_frozen_equals_unfrozen_on_shared_gradients(wide):
     for n in WATCH_ALWAYS:
         fro, mx = _errs(res[False][1][n], res[True][1][n])
         assert fro < 1.5e-2, (n, fro, mx)
+
+
+def test_bf16_7b_width_tail_rows_summed_by_the_norms_change_nothing(wide):
+    """K-sliced tail rows of o_proj / down_proj (forward) and of the qkv / gate|up dgrads (backward, frozen layers) left as fp32
+    slabs and summed by the RMSNorm kernel that reads them (EGOMI_EPI_SLABS, egomi_rmsnorm_fwd_tail / _bwd_tail) vs the separate
+    combine pass: the same bits reach the loss, the hidden state and the gradients."""
+    dims, toks, masks, Lp, pts, start, sd, ref = wide
+    res = {}
+    for fuse in (True, False):
+        m = _model(dims, sd, False)
+        m.engine.use_tail_fuse = fuse
+        loss = m.loss_and_backward(toks.cuda(), masks.cuda(), pts.cuda(), Lp, dims.tok.pad, fps_start=start)
+        with torch.no_grad():
+            hn = m.engine.forward_hidden(toks.cuda(), masks.cuda(), pts.cuda(), start, save=False).clone()
+        res[fuse] = (float(loss), hn, {n: m.engine.main_grad[n].clone() for n in ("model.point_proj.4.weight", "model.point_proj.0.weight", "lm_head.weight")})
+        del m
+        torch.cuda.empty_cache()
+    from egoscaler_amd import ops
+    d, M = dims.lm.hidden_size, B * toks.shape[1]
+    import ctypes
+    assert abs(res[True][0] - res[False][0]) <= 1e-6 * abs(res[False][0])             # the scalar loss is an atomic fp32 sum
+    assert torch.equal(res[True][1], res[False][1])
+    for n in res[True][2]:
+        assert torch.equal(res[True][2][n], res[False][2][n]), n
+    # not vacuous: the library does slice tail rows of these products at this size
+    a = torch.zeros(M, d, dtype=torch.bfloat16, device="cuda")
+    wt = torch.zeros(d, d, dtype=torch.bfloat16, device="cuda")
+    _, tail = ops.mm(a, wt, defer_tail=True)
+    assert tail is not None and tail[1] >= 2 and 0 < tail[0] < M, tail
