@@ -358,6 +358,85 @@ __global__ __launch_bounds__(256) void rope_vec8_kernel(T* x, const float* cos_t
     }
 }
 
+// rope_vec8_kernel for a q|k|v array [rows, 3*H*hd] whose rows >= row0 are still K-slice slabs of the qkv product (EGOMI_EPI_SLABS
+// on a large product): those rows are summed in slice order and rounded first (what the combine pass would have stored); q and k
+// get the rotation, v is only materialised.  Rows < row0: the plain in-place rotation of q and k.  Same arithmetic as
+// splitk_reduce_kernel followed by rope_vec8_kernel.
+template <typename T>
+__global__ __launch_bounds__(256) void rope_qkv_tail_kernel(T* x, const float* cos_tab, const float* sin_tab, long long rows, int S, int pos_offset, int H, int hd,
+                                                            long long ld, int row0, const float* slabs, int sk, long long slab_stride) {
+    const int half = hd >> 1, cpv = half >> 3;
+    const long long d = (long long)H * hd, ncols = 3 * d;
+    const long long total = rows * 3 * H * cpv;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const int i = (int)(e % cpv) * 8;
+        const int h = (int)((e / cpv) % H);
+        const int part = (int)((e / ((long long)cpv * H)) % 3);
+        const long long r = e / ((long long)cpv * H * 3);
+        const bool tail = r >= row0;
+        if (part == 2 && !tail) continue;
+        const long long col = part * d + (long long)h * hd + i;
+        T* p = x + r * ld + col;
+        float a[8], b[8], oa[8], ob[8];
+        if (tail) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { a[j] = 0.f; b[j] = 0.f; }
+            for (int s2 = 0; s2 < sk; ++s2) {
+                float t[8];
+                load8<float>(slabs + (long long)s2 * slab_stride + (r - row0) * ncols + col, t);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) a[j] += t[j];
+                load8<float>(slabs + (long long)s2 * slab_stride + (r - row0) * ncols + col + half, t);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) b[j] += t[j];
+            }
+            if (sizeof(T) == 2) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { a[j] = bf2f(f2bf(a[j])); b[j] = bf2f(f2bf(b[j])); }
+            }
+        } else {
+            load8<T>(p, a);
+            load8<T>(p + half, b);
+        }
+        if (part < 2) {
+            const int pos = pos_offset + (int)(r % S);
+            float c[8], sn[8];
+            load8<float>(cos_tab + (long long)pos * half + i, c);
+            load8<float>(sin_tab + (long long)pos * half + i, sn);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float cj = c[j], sj = sn[j];
+                if (sizeof(T) == 2) {
+                    cj = bf2f(f2bf(cj)); sj = bf2f(f2bf(sj));
+                    oa[j] = bf2f(f2bf(a[j] * cj)) + bf2f(f2bf(-b[j] * sj));
+                    ob[j] = bf2f(f2bf(b[j] * cj)) + bf2f(f2bf(a[j] * sj));
+                } else {
+                    oa[j] = a[j] * cj + (-b[j]) * sj;
+                    ob[j] = b[j] * cj + a[j] * sj;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { oa[j] = a[j]; ob[j] = b[j]; }
+        }
+        store8<T>(p, oa);
+        store8<T>(p + half, ob);
+    }
+}
+
+extern "C" int egomi_rope_qkv_tail(void* qkv, const float* cos_tab, const float* sin_tab, int64_t rows, int S, int pos_offset, int H, int hd, int64_t ld,
+                                   int row0, const float* slabs, int slices, int dtype, egomi_stream_t stream) {
+    if (!qkv || !cos_tab || !sin_tab) return EGOMI_E_BADARG;
+    if (rows <= 0 || S <= 0 || H <= 0 || hd <= 0 || (hd / 2) % 8 || ld % 8 || ld < 3ll * H * hd || pos_offset < 0 || row0 < 0 || row0 > rows) return EGOMI_E_SHAPE;
+    if (row0 < rows && (!slabs || slices < 1 || ((uintptr_t)slabs & 15))) return EGOMI_E_SHAPE;
+    if ((uintptr_t)qkv & 15) return EGOMI_E_SHAPE;
+    const long long tv = rows * 3 * H * (hd / 16);
+    const int gv = (int)((tv + 255) / 256 < 16384 ? (tv + 255) / 256 : 16384);
+    EGOMI_DISPATCH_DTYPE(dtype, EGOMI_LAUNCH(rope_qkv_tail_kernel<T>, dim3(gv), dim3(256), 0, (hipStream_t)stream, (T*)qkv, cos_tab, sin_tab, (long long)rows, S,
+                                             pos_offset, H, hd, (long long)ld, row0, slabs, slices, (long long)(rows - row0) * 3 * H * hd));
+    return egomi_launch_status();
+}
+
 extern "C" int egomi_rope(void* x, const float* cos_tab, const float* sin_tab, int64_t rows, int S, int pos_offset, int H, int hd,
                           int64_t ld, int inverse, int dtype, egomi_stream_t stream) {
     if (!x || !cos_tab || !sin_tab) return EGOMI_E_BADARG;

@@ -377,13 +377,20 @@ class Engine:
                 qkv, gu, rstd1, rstd2 = ws.get("qkv", (M, 3 * d), T), ws.get("gu", (M, 2 * Fd), T), None, None
             ops.rmsnorm(x, w[p + "input_layernorm.weight"], lm.rms_norm_eps, rstd=rstd1, out=h, tail=pend, tail_residual=pend_res)
             pend = pend_res = None
+            t_qkv = None
             if l in self.wqkv:
-                ops.mm(h, self.wqkv[l], out=qkv)
+                if defer:
+                    _, t_qkv = ops.mm(h, self.wqkv[l], out=qkv, defer_tail=True)
+                else:
+                    ops.mm(h, self.wqkv[l], out=qkv)
             else:
                 ops.mm(h, w[p + "self_attn.q_proj.weight"], out=qkv[:, :d])
                 ops.mm(h, w[p + "self_attn.k_proj.weight"], out=qkv[:, d:2 * d])
                 ops.mm(h, w[p + "self_attn.v_proj.weight"], out=qkv[:, 2 * d:])
-            ops.rope_(qkv, self.cos, self.sin, M, S, past, 2 * H, hd, 3 * d)          # q and k heads are adjacent columns
+            if t_qkv is not None:
+                ops.rope_qkv_tail_(qkv, self.cos, self.sin, M, S, past, H, hd, 3 * d, t_qkv)
+            else:
+                ops.rope_(qkv, self.cos, self.sin, M, S, past, 2 * H, hd, 3 * d)      # q and k heads are adjacent columns
             if kv_sink is not None:
                 kv_sink(l, qkv, B, S)
             lse = None

@@ -351,6 +351,14 @@ def rope_(x, cos, sin, rows, seq, pos_offset, H, hd, ld, inverse=False):
     return x
 
 
+def rope_qkv_tail_(qkv, cos, sin, rows, seq, pos_offset, H, hd, ld, tail):
+    """rope_ on the q and k heads of a stacked q|k|v array (H = heads of ONE of them) whose rows >= tail[0] are still the K-slice
+    slabs of the product (mm(..., defer_tail=True)): summed, rounded, rotated / materialised in this pass (egomi_rope_qkv_tail)."""
+    call("egomi_rope_qkv_tail", P(qkv), P(cos), P(sin), c_i64(rows), c_i(seq), c_i(pos_offset), c_i(H), c_i(hd), c_i64(ld), c_i(tail[0]), c_p(tail[2]),
+         c_i(tail[1]), c_i(dt(qkv.dtype)), S())
+    return qkv
+
+
 def swiglu(gate, up, out):
     rows, cols = gate.shape
     call("egomi_swiglu_fwd", P(gate), P(up), P(out), c_i64(rows), c_i(cols), c_i64(_ld(gate)), c_i64(_ld(out)), c_i(dt(gate.dtype)), S())

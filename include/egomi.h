@@ -310,6 +310,11 @@ int egomi_rmsnorm_bwd_tail(void* dy, const void* x, const void* w, const float* 
  * replaces HF rotate_half/apply_rotary_pos_emb, modeling_llama.py:130-160 (tables: :112-127) */
 int egomi_rope(void* x, const float* cos_tab, const float* sin_tab, int64_t rows, int S, int pos_offset, int H, int hd,
                int64_t ld, int inverse, int dtype, egomi_stream_t stream);
+/* Tail form for the stacked q|k|v product [rows, 3*H*hd]: rows >= row0 are still `slices` K-slice slabs (EGOMI_EPI_SLABS,
+ * egomi_gemm_tail_plan); they are summed, rounded and written (q, k rotated; v as is); rows < row0 get egomi_rope's rotation of
+ * q and k in place.  Bit-identical to the combine pass followed by egomi_rope on the first 2*H heads. */
+int egomi_rope_qkv_tail(void* qkv, const float* cos_tab, const float* sin_tab, int64_t rows, int S, int pos_offset, int H, int hd, int64_t ld,
+                        int row0, const float* slabs, int slices, int dtype, egomi_stream_t stream);
 
 /* SwiGLU: out = silu(gate)*up.  replaces HF LlamaMLP.forward, modeling_llama.py:174-176.
  * gate/up [rows, cols] with row stride ld_in; out / dgate / dup row stride ld_out; dact row stride ld_act. */
