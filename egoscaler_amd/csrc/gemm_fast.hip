@@ -1119,8 +1119,13 @@ static TailPlan tail_plan_for(const egomi_gemm_desc* d) {
 extern "C" int egomi_gemm_tail_plan(const egomi_gemm_desc* d0, int* row0, int* slices) {
     if (!d0 || !row0 || !slices) return EGOMI_E_BADARG;
     *row0 = d0->M; *slices = 0;
-    if (d0->force_generic || !fast_applicable(d0) || tile_choice(d0) != 8) return EGOMI_E_UNSUPPORTED;
+    // the plan is asked BEFORE the caller sets epilogue = EGOMI_EPI_SLABS; the launch that follows carries it, and tile_choice looks at
+    // the epilogue (its few-tiles / long-K rule wants a plain one): evaluate the descriptor the launch will see, so that plan and launch
+    // agree for every M (M in [1024, 1792] at K >= 8192 used to plan the 256x256 kernel and launch the 128x128 one)
     egomi_gemm_desc dl = *d0;
+    dl.epilogue = EGOMI_EPI_SLABS;
+    if (dl.force_generic || !fast_applicable(&dl) || tile_choice(&dl) != 8) return EGOMI_E_UNSUPPORTED;
+    if (dl.bias || dl.accumulate || dl.act != 0 || dl.alpha != 1.0f || dl.c_dtype != EGOMI_BF16 || (dl.N & 7)) return EGOMI_E_UNSUPPORTED;
     if (dl.ws_tickets_zeroed && dl.workspace) {
         if (dl.workspace_bytes > 4096) { dl.workspace = (char*)dl.workspace + 4096; dl.workspace_bytes -= 4096; }
         else { dl.workspace = nullptr; dl.workspace_bytes = 0; }

@@ -33,6 +33,15 @@ def argmax_rows(logits, ids, seq=None, pos=0):
          c_i(pos), c_i(dt(logits.dtype)), S())
 
 
+def sample_rows(logits, scores, seq, pos, rep_from, ids, done, repetition_penalty, temperature, top_k, top_p, do_sample, rng, draw, eos, pad):
+    """One step's token choice for the whole batch (include/egomi.h egomi_sample_rows): processed scores (HF's `.scores`) + next token."""
+    B, V = logits.shape
+    call("egomi_sample_rows", P(logits), c_i64(logits.stride(0)), c_i(B), c_i(V), P(scores), c_i64(scores.stride(0)), P(seq),
+         c_i64(seq.stride(0) if seq is not None else 0), c_i(pos), c_i(rep_from), P(ids), P(done), c_f(repetition_penalty), c_f(temperature),
+         c_i(int(top_k or 0)), c_f(top_p), c_i(int(bool(do_sample))), P(rng), c_i(draw), c_i64(-1 if eos is None else int(eos)),
+         c_i64(0 if pad is None else int(pad)), c_i(dt(logits.dtype)), S())
+
+
 class Decoder:
     def __init__(self, engine, B, max_len):
         self.eng, self.B, self.Smax = engine, B, max_len
@@ -159,6 +168,42 @@ class Decoder:
         if not normed:
             ops.rmsnorm(x, w["model.norm.weight"], lm.rms_norm_eps, out=self.hn)
         ops.mm(self.hn, w["lm_head.weight"], out=self.lg)
+
+    def sample(self, T_new, do_sample=True, temperature=1.0, top_k=50, top_p=0.95, repetition_penalty=1.0, eos=None, pad=None, seed=None,
+               use_graph=True):
+        """After prefill(): T_new steps of HF generate's token loop (model_arch.py:82-108 -> GenerationMixin: logits processors, warpers,
+        multinomial / arg-max, eos bookkeeping), every step one egomi_sample_rows launch + one cached decode step, all of them captured
+        into ONE hipGraph (the draw counter and `pos` are launch constants, seed and done flags live in device memory).
+        Returns (sequences [B, S0+T_new], processed scores fp32 [T_new, B, V]); rows that emitted `eos` continue with `pad`."""
+        S0, dev = self.pos, self.eng.device
+        V = self.lg.shape[1]
+        sc_buf = torch.empty(T_new, self.B, V, dtype=torch.float32, device=dev)
+        if seed is None:
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item())            # the CPU default generator: torch.manual_seed() makes a run repeatable
+        self.rng = torch.tensor([int(seed), 0], dtype=torch.int64).to(dev)
+        self.done = torch.zeros(self.B, dtype=torch.int32, device=dev) if eos is not None else None
+        kw = dict(repetition_penalty=float(repetition_penalty or 1.0), temperature=float(temperature or 1.0), top_k=int(top_k or 0),
+                  top_p=float(1.0 if top_p is None else top_p), do_sample=bool(do_sample), rng=self.rng, eos=eos, pad=pad)
+
+        def steps():
+            for t in range(T_new):
+                sample_rows(self.lg, sc_buf[t], self.seq, S0 + t, 0, self.tok.view(-1), self.done, draw=t, **kw)
+                if t + 1 < T_new:
+                    self.step(S0 + t)
+        if not use_graph:
+            steps()
+        else:
+            g = torch.cuda.CUDAGraph()
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                with torch.cuda.graph(g, stream=side):
+                    steps()
+            torch.cuda.current_stream().wait_stream(side)
+            g.replay()
+            self.graph = g
+        self.pos = S0 + T_new
+        return self.seq, sc_buf
 
     def greedy(self, T_new, use_graph=True, keep_scores=True):
         """After prefill(): T_new greedy tokens.  Returns (sequences [B,S0+T], scores list or None)."""

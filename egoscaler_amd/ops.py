@@ -242,7 +242,10 @@ def gemm_raw(A, B, C, M, N, K, lda, ldb, ldc, a_layout=0, b_layout=0, bias=None,
         row0, slices = c_i(0), c_i(0)
         if _lib.lib().egomi_gemm_tail_plan(ctypes.byref(d), ctypes.byref(row0), ctypes.byref(slices)) == 0 and slices.value >= 2:
             d.epilogue = 2
-            tail = (row0.value, slices.value, d.workspace + (4096 if d.ws_tickets_zeroed else 0))
+            if _lib.lib().egomi_gemm_kernel_id(ctypes.byref(d)) == 2:    # the launch must take the kernel the plan was made for
+                tail = (row0.value, slices.value, d.workspace + (4096 if d.ws_tickets_zeroed else 0))
+            else:
+                d.epilogue = 0
     prof = PROFILER
     flops = 2.0 * M * N * K * max(1, batch)
     kid = _lib.lib().egomi_gemm_kernel_id(ctypes.byref(d)) if (prof is not None and prof.enabled and flops >= prof.min_flops) else None

@@ -361,13 +361,18 @@ class TrajPointLLMForCausalLM(nn.Module):
     @torch.no_grad()
     def generate(self, input_ids=None, attention_mask=None, point_clouds=None, max_length=20, temperature=1.0, top_k=50,
                  top_p=0.95, repetition_penalty=1.0, do_sample=True, num_return_sequences=1, fps_start=None,
-                 eos_token_id=None, pad_token_id=None, **kwargs):
-        """model_arch.py:77-108: `max_length` means max_new_tokens; returns .sequences [B,S0+T] and
-        .scores (T x [B,V]).  Prefill runs encoder + splice and fills the KV cache; every later step
-        feeds one token (the behaviour pointllm.py:112,255-275 intends; see DESIGN.md on the
-        reference's cache bug).  do_sample=False is greedy arg-max and is what parity pins.  `repetition_penalty` and
-        `num_return_sequences` follow HF's logits processor / input expansion (model_arch.py:86-88 hands them through)."""
-        from ..decode import Decoder, argmax_rows
+                 eos_token_id="config", pad_token_id=None, seed=None, **kwargs):
+        """model_arch.py:77-108: `max_length` means max_new_tokens; returns .sequences [B,S0+T'] and .scores (T' x [B,V], the PROCESSED
+        scores, as HF returns them with output_scores=True).  Prefill runs encoder + splice and fills the KV cache; every later step
+        feeds one token (the behaviour pointllm.py:112,255-275 intends; see DESIGN.md on the reference's cache bug).
+
+        Every mode runs on the device under one hipGraph (decode.Decoder.sample -> egomi_sample_rows): repetition penalty, temperature,
+        top-k, top-p in HF's order and with HF's tie rules (golden: tests/golden/sampling.npz, recorded from HF's own processors on the
+        reference model's logits), a draw from the softmax (Gumbel-max on a counter-based generator seeded from torch's CPU generator —
+        torch.multinomial's stream cannot be reproduced, so parity is on `.scores` and, with do_sample=False, on the ids), and HF's
+        eos rule: `eos_token_id` defaults to the config's (GenerationConfig.from_model_config), finished rows emit `pad_token_id`, and
+        the outputs are cut after the step at which every row has finished.  eos_token_id=None: fixed length, never stops."""
+        from ..decode import Decoder
         eng = self.engine
         dev = eng.device
         ids = input_ids.to(dev)
@@ -383,46 +388,27 @@ class TrajPointLLMForCausalLM(nn.Module):
             fps_start = None if fps_start is None else torch.as_tensor(fps_start).to(dev).repeat_interleave(n_ret, 0)
         B, S0 = ids.shape
         T = int(max_length)
+        if isinstance(eos_token_id, str):
+            eos_token_id = self.dims.tok.eos
+        if eos_token_id is not None and pad_token_id is None:
+            pad_token_id = self.dims.tok.pad if self.dims.tok.pad is not None else eos_token_id     # HF: pad defaults to eos when the config has none
+        for name, v in (("temperature", temperature), ("repetition_penalty", repetition_penalty)):
+            if v is not None and not float(v) > 0:
+                raise ValueError(f"`{name}` has to be a strictly positive float, but is {v}")               # logits_process.py:239,307
+        if top_p is not None and not (0 < float(top_p) <= 1.0):
+            raise ValueError(f"`top_p` has to be a float > 0 and < 1, but is {top_p}")
         dec = Decoder(eng, B, S0 + T)
-        lg = dec.prefill(ids, attention_mask, point_clouds, fps_start, T)
-        rp = float(repetition_penalty or 1.0)
-        if not do_sample and eos_token_id is None and rp == 1.0:
-            # greedy, fixed length: all T steps captured into one hipGraph (use_graph) and replayed
-            seq, scores = dec.greedy(T, use_graph=kwargs.get("use_graph", True))
-            return GenerateOutput(sequences=seq, scores=tuple(scores))
-        seq, scores = ids, []
-        done = torch.zeros(B, dtype=torch.bool, device=dev)
-        for t in range(T):
-            lgf = lg.float()
-            if rp != 1.0:                                  # HF RepetitionPenaltyLogitsProcessor: tokens already in the sequence
-                prev = torch.gather(lgf, 1, seq)
-                lgf = lgf.scatter(1, seq, torch.where(prev < 0, prev * rp, prev / rp))
-            if do_sample:
-                s = lgf / max(float(temperature or 1.0), 1e-6)
-                if top_k:
-                    kth = torch.topk(s, min(int(top_k), s.shape[-1]), dim=-1)[0][:, -1:]
-                    s = s.masked_fill(s < kth, float("-inf"))
-                if top_p and top_p < 1.0:
-                    sv, si = torch.sort(s, descending=False, dim=-1)
-                    cp = sv.softmax(-1).cumsum(-1)
-                    rm = cp <= (1 - top_p)
-                    rm[:, -1:] = False
-                    s = s.masked_fill(rm.scatter(1, si, rm), float("-inf"))
-                scores.append(s)
-                nxt = torch.multinomial(s.softmax(-1), 1)
-            else:
-                scores.append(lgf.clone())
-                nxt = lgf.argmax(-1, keepdim=True)
-            if eos_token_id is not None:
-                nxt = torch.where(done[:, None], torch.full_like(nxt, pad_token_id if pad_token_id is not None else eos_token_id), nxt)
-                done = done | (nxt[:, 0] == eos_token_id)
-            seq = torch.cat([seq, nxt], 1)
-            if t + 1 == T or (eos_token_id is not None and bool(done.all())):
-                break
-            dec.tok.copy_(nxt)
-            dec.step(S0 + t)
-            lg = dec.lg
-        return GenerateOutput(sequences=seq, scores=tuple(scores))
+        dec.prefill(ids, attention_mask, point_clouds, fps_start, T)
+        if not do_sample:                                  # HF applies the warpers (temperature / top-k / top-p) in sampling mode only
+            temperature, top_k, top_p = 1.0, 0, 1.0
+        seq, sc = dec.sample(T, do_sample=do_sample, temperature=temperature, top_k=top_k, top_p=top_p, repetition_penalty=repetition_penalty,
+                             eos=eos_token_id, pad=pad_token_id, seed=seed, use_graph=kwargs.get("use_graph", True))
+        stop = T
+        if eos_token_id is not None and T > 0:             # HF leaves the loop after the step at which the last unfinished row emitted eos
+            hit = seq[:, S0:] == eos_token_id
+            first = torch.where(hit.any(1), hit.int().argmax(1), torch.full((B,), T - 1, device=dev))
+            stop = int(first.max()) + 1
+        return GenerateOutput(sequences=seq[:, :S0 + stop], scores=tuple(sc[t] for t in range(stop)))
 
     def train(self, mode: bool = True):
         """model_arch.py:110-124: frozen parts stay in eval(); embed_tokens follows `mode`."""

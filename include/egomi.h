@@ -230,6 +230,24 @@ int egomi_attn_decode(const void* q, int64_t ld_q, const void* kcache, const voi
                       egomi_stream_t stream);
 int egomi_argmax_rows(const void* logits, int64_t ld, int B, int V, int64_t* ids, int64_t* seq, int64_t ld_seq, int pos, int dtype,
                       egomi_stream_t stream);
+/* sample_rows: everything HF GenerationMixin.generate does between two forward passes under the arguments the reference passes
+ * (models/pointllm/model_arch.py:82-108: do_sample=True, top_k=50, top_p=0.95, temperature, repetition_penalty,
+ * output_scores=True, return_dict_in_generate=True; train.py:223-228 validates this way), for a whole batch in one launch:
+ *   scores[b, :] = TopP(TopK(Temperature(RepetitionPenalty(logits[b, :]))))   fp32, -inf where a warper removed the token
+ *                  (transformers/generation/logits_process.py: RepetitionPenaltyLogitsProcessor on the tokens seq[b, rep_from:pos],
+ *                  TemperatureLogitsWarper, TopKLogitsWarper — ties with the k-th value kept —, TopPLogitsWarper — ascending stable
+ *                  order, prefix with cumulative probability <= 1 - top_p removed, min_tokens_to_keep = 1)
+ *   ids[b]       = do_sample ? a draw from softmax(scores[b, :]) (Gumbel-max on Philox4x32-10 bits keyed by rng[0] = seed and
+ *                  rng[1] + draw = draw counter, both read from DEVICE memory at run time so that a replayed hipGraph draws fresh
+ *                  numbers; replaces torch.multinomial, whose stream cannot be reproduced) : argmax (lowest index on ties)
+ *   done[b]      (may be NULL) HF's unfinished_sequences: a finished row emits pad_id, a row finishes when it emits eos_id (< 0: never)
+ *   seq[b*ld_seq + pos] = ids[b]  (may be NULL)
+ * top_k = 0 / top_p = 1 / temperature = 1 / repetition_penalty = 1 switch the respective step off.  `pos`, `draw` are launch
+ * constants (no length is read from device memory), so T steps can be captured into one hipGraph. */
+int egomi_sample_rows(const void* logits, int64_t ld, int B, int V, float* scores, int64_t ld_scores, int64_t* seq, int64_t ld_seq,
+                      int pos, int rep_from, int64_t* ids, int* done, float repetition_penalty, float temperature, int top_k,
+                      float top_p, int do_sample, const uint64_t* rng, int draw, int64_t eos_id, int64_t pad_id, int dtype,
+                      egomi_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * A14  trajectory <-> token ids for whole batches, displacement metrics (integer contracts bit-exact).

@@ -51,8 +51,7 @@ WATCH_LAYERS = [f"model.layers.{l}.{n}" for l in range(LAYERS) for n in
                  "post_attention_layernorm.weight")]
 
 
-@pytest.fixture(scope="module")
-def wide():
+def _reference(B):
     """Inputs, bf16-rounded weights and the fp32 oracle's loss / hidden / gradients (one CPU pass, every LLM weight trainable:
     the frozen mode's gradients are a subset of the same numbers)."""
     from oracle import pointllm as OPL, llama as OL
@@ -74,6 +73,18 @@ def wide():
     return dims, toks, masks, Lp, pts, start, sd, ref
 
 
+@pytest.fixture(scope="module")
+def wide():
+    return _reference(B)
+
+
+@pytest.fixture(scope="module")
+def wide_b2():
+    """bs = 2 per rank (M = 1384): the default --bs 8 on 4 GPUs, --grad_accum_steps 4, a 2-3 sample validation prefill.  ADVICE r2:
+    M in [1024, 1792] made the tail plan and the launch disagree on the kernel and egomi_gemm failed; no test used such an M."""
+    return _reference(2)
+
+
 def _model(dims, sd, unfreeze):
     from egoscaler_amd.pointllm import TrajPointLLMForCausalLM
     args = types.SimpleNamespace(unfreeze_pc_encoder=False, unfreeze_language_model=unfreeze, num_bins=dims.tok.num_bins, model_name=None)
@@ -84,6 +95,15 @@ def _model(dims, sd, unfreeze):
 
 @pytest.mark.parametrize("unfreeze", [False, True], ids=["frozen_llm", "unfrozen_llm"])
 def test_bf16_7b_width_step_matches_fp32_oracle(wide, unfreeze):
+    _check_step(wide, unfreeze)
+
+
+@pytest.mark.parametrize("unfreeze", [False, True], ids=["frozen_llm", "unfrozen_llm"])
+def test_bf16_7b_width_step_matches_fp32_oracle_at_two_samples_per_rank(wide_b2, unfreeze):
+    _check_step(wide_b2, unfreeze)
+
+
+def _check_step(wide, unfreeze):
     from egoscaler_amd import ops
     dims, toks, masks, Lp, pts, start, sd, ref = wide
     m = _model(dims, sd, unfreeze)
@@ -98,7 +118,10 @@ def test_bf16_7b_width_step_matches_fp32_oracle(wide, unfreeze):
 
     # ---- the kernels the bench measures were the ones that ran
     n8 = len(prof.recs)
-    assert n8 >= (8 if not unfreeze else 8) * LAYERS, f"8-phase GEMM launches: {n8}"      # fwd qkv,o,gate|up,down + their dgrads per layer
+    if toks.shape[0] >= 8:
+        assert n8 >= 8 * LAYERS, f"8-phase GEMM launches: {n8}"      # fwd qkv,o,gate|up,down + their dgrads per layer
+    else:
+        assert n8 >= 2 * LAYERS, f"8-phase GEMM launches: {n8}"      # M = 1384: the long-K products (down_proj, the K-concatenated dgrads)
     assert eng.use_fused_attention and eng.dtype == torch.bfloat16 and dims.lm.head_dim == 128
     if not unfreeze:
         assert sorted(eng.wqkv) == sorted(eng.wgu) == sorted(eng.wqkvT) == sorted(eng.wguT) == list(range(LAYERS))
