@@ -29,6 +29,15 @@ def shard_range(global_batch: int, rank: int, world: int):
     return rank * per, (rank + 1) * per
 
 
+def ragged_shard_range(n: int, rank: int, world: int):
+    """Contiguous shard [lo, hi) of n items that need not divide over the ranks (the short last batch of a validation pass: the
+    reference's val / test DataLoader has no drop_last, train.py:79-82): the first n % world ranks take one item more; a rank may
+    get an empty range."""
+    base, extra = divmod(int(n), int(world))
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
 def _cast(src, dst):
     """dst <- src (dtype change allowed).  Device tensors go through libegomi's vector cast; host tensors (gloo
     rehearsal of the N>1 logic on CPUs) through torch."""
@@ -76,7 +85,13 @@ class GradSync:
                                                    # order on ONE side stream, so buckets of equal size share their scratch
         self.stats = {"buckets": 0, "collective_calls": 0, "wire_bytes": 0}
         self._bucket_id = 0
-        self._a2a_ok = True
+        # capability, decided ONCE from the backend's name (never by catching an exception around the real exchange: a rank-local
+        # failure would send that rank down the other branch while its peers sit in the first collective — ADVICE r2).  RCCL ("nccl")
+        # has all-to-all, and so has gloo for host tensors; gloo with DEVICE tensors (two ranks rehearsing on one card) has not and
+        # gathers everything instead.  On RCCL every error of a collective propagates.
+        self.backend = dist.get_backend(group) if dist.is_initialized() else None
+        self.time_exposed = False                  # bench.py: event pair around finish()'s join = what the exchange costs the step
+        self._exposed = []
 
     # ------------------------------------------------------------------ bucket assembly
     def begin_step(self):
@@ -157,13 +172,10 @@ class GradSync:
         self.stats["buckets"] += 1
 
     def _all_to_all(self, recv, send, W, c):
-        if self._a2a_ok:
-            try:
-                dist.all_to_all_single(recv, send, group=self.group)
-                return
-            except (RuntimeError, NotImplementedError):
-                self._a2a_ok = False                          # backend without all-to-all: gather everything, keep my chunk column
-        full = [torch.empty_like(send) for _ in range(W)]
+        if self.backend != "gloo" or not send.is_cuda:
+            dist.all_to_all_single(recv, send, group=self.group)
+            return
+        full = [torch.empty_like(send) for _ in range(W)]        # gloo + device tensors only: gather everything, keep my chunk column
         dist.all_gather(full, send, group=self.group)
         for w in range(W):
             recv[w * c:(w + 1) * c].copy_(full[w][self.rank * c:(self.rank + 1) * c])
@@ -194,7 +206,22 @@ class GradSync:
     def finish(self):
         self.flush()
         if self.stream is not None:
-            torch.cuda.current_stream().wait_stream(self.stream)
+            cur = torch.cuda.current_stream()
+            if self.time_exposed:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(cur)
+                cur.wait_stream(self.stream)
+                e1.record(cur)
+                self._exposed.append((e0, e1))
+            else:
+                cur.wait_stream(self.stream)
+
+    def exposed_ms(self):
+        """Mean time the compute stream spent waiting for the exchange in finish() (time_exposed=True), per step."""
+        if not self._exposed:
+            return None
+        torch.cuda.synchronize()
+        return sum(a.elapsed_time(b) for a, b in self._exposed) / len(self._exposed)
 
     @property
     def grad_scale(self):

@@ -23,7 +23,7 @@ import torch
 import torch.distributed as dist
 
 from . import ops, synth, traj as T
-from .dp import GradSync, shard_range
+from .dp import GradSync, shard_range, ragged_shard_range
 from .optim import EgoAdamW, linear_warmup_lr
 
 
@@ -156,10 +156,17 @@ def run_validation(model, data, args, device, max_batches=None):
     model.eval()
     sums = np.zeros(5)                                   # ADE, FDE, ADE_as_called, GD, n
     dump = {}
-    nb = len(data) // (per * world)
+    # the reference's val / test DataLoader (train.py:79-82, evaluate.py:93-100: batch_size=bs, shuffle=False, NO drop_last) keeps the
+    # short last batch: every sample is generated for and lands in the dump.  A batch is dealt over the ranks; the short one is split
+    # raggedly and a rank whose share is empty skips it (the only collective of this pass is the all-reduce of the sums below)
+    gb = per * world
+    nb = -(-len(data) // gb)
     for bi in range(nb if max_batches is None else min(nb, max_batches)):
-        lo, hi = shard_range(per * world, rank, world)
-        idx = list(range(bi * per * world + lo, bi * per * world + hi))
+        n_here = min(gb, len(data) - bi * gb)
+        lo, hi = shard_range(gb, rank, world) if n_here == gb else ragged_shard_range(n_here, rank, world)
+        idx = list(range(bi * gb + lo, bi * gb + hi))
+        if not idx:
+            continue
         batch = data.batch(idx, device, args.max_traj_token)
         prompts, tokens = batch["prompts"], batch["tokens"]
         max_new = tokens.shape[1] - prompts.shape[1]
@@ -196,14 +203,20 @@ def run_validation(model, data, args, device, max_batches=None):
     return {"ADE": mean(0), "FDE": mean(1), "ADE_as_called": mean(2), "GD": mean(3), "n": int(sums[4])}, dump
 
 
-def train(args, model, train_data, val_data=None, device="cuda", log=print):
-    """train.py:129-310.  Returns the list of per-epoch records.
+def train(args, model, train_data, val_data=None, device="cuda", log=print, step_log=None):
+    """train.py:129-310.  Returns the list of per-epoch records.  step_log (optional): called once per optimizer step with
+    {"epoch", "step", "learning_rate", "loss"} — the reference's per-step wandb.log (train.py:186-193; reading the loss syncs, as its
+    `loss.item()` does).
 
     Batch arithmetic (train.py:92-96): `--bs` is the optimizer batch of the whole job; each rank runs
     `--grad_accum_steps` micro-batches of ceil(bs / accum / world) samples per optimizer step, gradients accumulate in the
     fp32 main_grad buffers, ONE gradient sync + ONE AdamW step follow the last micro-batch (grad scale 1/(accum*world)).
     LR: HF linear schedule with warm-up over int(total/5) steps then decay to 0 (train.py:113-116), advanced once per
-    optimizer step."""
+    optimizer step, `total` = optimizer steps of the run.  DEVIATION for --grad_accum_steps > 1: the reference sizes the
+    schedule in LOADER iterations (num_training_steps = epochs * len(train_dataloader), train.py:114-116) while DeepSpeed advances it
+    once per accumulation boundary, so there the warm-up lasts accum x longer and the rate never decays to zero (it ends at
+    1 - 1/accum of the way down).  Here the schedule always spans the optimizer steps actually taken; with accum == 1 (the
+    reference's default) the two agree step by step (tests/test_host_glue.py pins both statements against HF's scheduler)."""
     rank, world = _rank_world()
     accum = max(1, int(getattr(args, "grad_accum_steps", 1) or 1))
     micro = micro_batch_per_rank(args.bs, accum, world)
@@ -247,7 +260,10 @@ def train(args, model, train_data, val_data=None, device="cuda", log=print):
             model.accumulate_grads = False
             if sync is not None:
                 sync.finish()
-            opt.step(grad_scale=1.0 / (accum * world), lr=linear_warmup_lr(float(args.lr_llm), global_step, total_steps))
+            lr_now = linear_warmup_lr(float(args.lr_llm), global_step, total_steps)
+            opt.step(grad_scale=1.0 / (accum * world), lr=lr_now)
+            if step_log is not None:
+                step_log({"epoch": epoch, "step": global_step, "learning_rate": lr_now, "loss": float(loss) if accum == 1 else None})
             global_step += 1
         rec = {"epoch": epoch, "train_loss": float(run) / max(1, steps_per_epoch), "global_step": global_step,
                "learning_rate": linear_warmup_lr(float(args.lr_llm), global_step, total_steps)}

@@ -62,6 +62,8 @@ class Engine:
                                                                                       # kernel runs (tests and A/B runs switch it off)
         self.use_tail_fuse = os.environ.get("EGOMI_NO_TAIL_FUSE", "0") != "1"         # K-sliced tail rows summed by the RMSNorm that reads them
         self.pb_trainer = None
+        self.defer_splice_check = False     # hipGraph capture of a whole step: the marker verdict is copied to pinned memory by the graph and
+        self.pending_splice = None          # looked at by the caller after the replay (check_pending_splice) instead of inside the forward pass
         self.pb_train_mode = False          # set by TrajPointLLMForCausalLM.train(): point backbone in train() mode
         self.prepared_bn_stale = False
 
@@ -435,7 +437,10 @@ class Engine:
         if save:
             ctx.update(x_last=x, rstd_f=rstd_f, hn=hn, key_mask=key_mask)
             self.ctx = ctx
-        self._check_splice_err(pending_err)
+        if self.defer_splice_check:
+            self.pending_splice = pending_err
+        else:
+            self._check_splice_err(pending_err)
         return hn
 
     def _stash_splice_err(self, err):
@@ -446,10 +451,15 @@ class Engine:
             host = self._splice_host[err.numel()] = torch.empty(err.numel(), dtype=torch.int32).pin_memory() if err.is_cuda else torch.empty(err.numel(), dtype=torch.int32)
         host.copy_(err, non_blocking=True)
         ev = None
-        if err.is_cuda:
+        if err.is_cuda and not self.defer_splice_check:
             ev = torch.cuda.Event()
             ev.record()
         return host, ev
+
+    def check_pending_splice(self):
+        """defer_splice_check mode: raise what the forward pass would have raised (call after the stream has been synchronised)."""
+        p, self.pending_splice = self.pending_splice, None
+        self._check_splice_err(p)
 
     @staticmethod
     def _check_splice_err(pending):

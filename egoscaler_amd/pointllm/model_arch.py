@@ -46,10 +46,56 @@ class PointLLMConfig:
         self.point_bert = None            # optional dict overriding the PointBERT YAML values
         self.__dict__.update(kw)
 
+    # PointBERT shapes by `point_backbone_config_name` (pointllm.py:38-41 resolves the name to a YAML next to its own sources; the numbers
+    # of the two YAMLs the reference ships: pointbert/PointTransformer_8192point_2layer.yaml:1-16, PointTransformer_base_8192point.yaml:1-13)
+    POINTBERT_BY_NAME = {
+        "PointTransformer_8192point_2layer": dict(trans_dim=384, depth=12, num_heads=6, group_size=32, num_group=512, encoder_dims=256,
+                                                  projection_hidden_dim=[1024, 2048], npoints=8192, drop_path_rate=0.1),
+        "PointTransformer_base_8192point": dict(trans_dim=1152, depth=12, num_heads=12, group_size=48, num_group=512, encoder_dims=512,
+                                                projection_hidden_dim=[], npoints=8192, drop_path_rate=0.1),
+    }
+
     @classmethod
-    def from_pretrained(cls, path):
+    def from_pretrained(cls, path, **overrides):
+        """Reads the config.json of an HF directory — written by this class OR by the reference's own `save_pretrained` (HF PretrainedConfig:
+        extra fields such as `architectures`, `dtype`, `transformers_version`, `head_dim`, `hidden_act` are kept as plain attributes;
+        transformers >= 5 nests rope_theta under `rope_parameters`, 4.x wrote it at top level).  `point_backbone_config_name` selects the
+        PointBERT shapes like the reference's YAML lookup (pointllm.py:38-41); a `<name>.yaml` inside the directory, or `point_bert=...`
+        here / in the JSON, overrides the two names the reference ships."""
         with open(os.path.join(path, "config.json")) as f:
-            return cls(**json.load(f))
+            kw = json.load(f)
+        rp = kw.get("rope_parameters")
+        if isinstance(rp, dict) and "rope_theta" in rp and "rope_theta" not in kw:
+            kw["rope_theta"] = float(rp["rope_theta"])
+            if rp.get("rope_type", "default") != "default":
+                raise NotImplementedError(f"rope_type {rp.get('rope_type')!r}: only the default rotary embedding is built")
+        if kw.get("rope_scaling"):
+            raise NotImplementedError("rope_scaling is not built (the reference's checkpoints do not use it)")
+        nkv = kw.get("num_key_value_heads")
+        if nkv is not None and nkv != kw.get("num_attention_heads", nkv):
+            raise NotImplementedError("grouped-query attention (num_key_value_heads != num_attention_heads) is not built")
+        if kw.get("hidden_act", "silu") != "silu" or kw.get("attention_bias") or kw.get("mlp_bias") or kw.get("tie_word_embeddings"):
+            raise NotImplementedError("config asks for a LLaMA variant this build does not have (hidden_act / biases / tied embeddings)")
+        kw.update(overrides)
+        cfg = cls(**kw)
+        if cfg.point_bert is None:
+            name = cfg.point_backbone_config_name
+            yml = os.path.join(path, f"{name}.yaml")
+            if os.path.exists(yml):
+                import yaml
+                with open(yml) as f:
+                    y = yaml.safe_load(f)
+                mdl = y.get("model", {})
+                keys = ("trans_dim", "depth", "num_heads", "group_size", "num_group", "encoder_dims", "drop_path_rate")
+                cfg.point_bert = {k: mdl[k] for k in keys if k in mdl}
+                cfg.point_bert["projection_hidden_dim"] = list(mdl.get("projection_hidden_dim", [])) if mdl.get("projection_hidden_layer", 0) else []
+                if "npoints" in y:
+                    cfg.point_bert["npoints"] = y["npoints"]
+            elif name in cls.POINTBERT_BY_NAME:
+                cfg.point_bert = dict(cls.POINTBERT_BY_NAME[name])
+            else:
+                raise ValueError(f"unknown point_backbone_config_name {name!r}: put {name}.yaml into {path} or pass point_bert=dict(...)")
+        return cfg
 
     def save_pretrained(self, path):
         os.makedirs(path, exist_ok=True)

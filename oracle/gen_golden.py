@@ -699,8 +699,141 @@ def gen_tiny_trained():
     RPL.cfg_from_yaml_file = orig_cfg
 
 
+def gen_sampling():
+    """The reference's DEFAULT generation mode (model_arch.py:82-108: do_sample=True, top_k=50, top_p=0.95, temperature, repetition_penalty,
+    output_scores=True): HF returns the PROCESSED scores, so they can be pinned without any RNG parity.  The processors are HF's own
+    objects in HF's own order: GenerationMixin._get_logits_processor (the method the reference's class inherits unmodified) builds the
+    list from a GenerationConfig carrying the reference's arguments; it is applied to the logits of the reference model recorded in
+    tiny_model.npz (`gen_scores`: the reference's forward on the growing sequence, gen_tiny_model above) and to tie-heavy variants
+    (bf16-rounded logits — what a bf16 lm_head produces — and logits quantised to 0.5, which put runs of equal values on both the k-th
+    value and the top-p boundary)."""
+    from transformers import LlamaConfig, LlamaForCausalLM, GenerationConfig
+    from oracle import sampling as OS
+    g = np.load(os.path.join(GOLD, "tiny_model.npz"), allow_pickle=False)
+    raw = torch.from_numpy(g["gen_scores"]).float()                 # [B, T, V] raw next-token logits of the reference model
+    seqs = torch.from_numpy(g["gen_sequences"])                     # [B, Lp + T]
+    Lp = int(g["prompt_len"])
+    B, T, V = raw.shape
+    host = LlamaForCausalLM(LlamaConfig(hidden_size=16, intermediate_size=16, num_hidden_layers=1, num_attention_heads=2, vocab_size=V))
+
+    def hf(logits, ids, **kw):
+        cfg = GenerationConfig(do_sample=True, **kw)
+        procs = host._get_logits_processor(generation_config=cfg, input_ids_seq_length=ids.shape[1], encoder_input_ids=None,
+                                           prefix_allowed_tokens_fn=None, logits_processor=None, device="cpu", model_kwargs={})
+        return procs(ids, logits.clone()), [type(p).__name__ for p in procs]
+
+    rng = np.random.Generator(np.random.Philox(key=7))
+    cases = []
+    for t in (0, 4, 9):
+        ids = seqs[:, :Lp + t]
+        cases.append((f"defaults_t{t}", raw[:, t], ids, dict(temperature=1.0, top_k=50, top_p=0.95, repetition_penalty=1.0)))
+        cases.append((f"all_t{t}", raw[:, t], ids, dict(temperature=0.7, top_k=20, top_p=0.8, repetition_penalty=1.3)))
+        cases.append((f"bf16_t{t}", raw[:, t].bfloat16().float(), ids, dict(temperature=1.0, top_k=50, top_p=0.95, repetition_penalty=1.0)))
+    q = (raw[:, 3] * 2).round() / 2                                  # values on a 0.5 grid: long runs of ties
+    wide = torch.from_numpy(rng.normal(0, 2.0, size=(3, 33000)).astype(np.float32)).bfloat16().float()    # V > 32768: the kernel's non-register path
+    ids0 = seqs[:, :Lp]
+    cases += [("ties_k50_p95", q, ids0, dict(temperature=1.0, top_k=50, top_p=0.95, repetition_penalty=1.0)),
+              ("ties_k7_p50_rp", q, ids0, dict(temperature=1.0, top_k=7, top_p=0.5, repetition_penalty=1.5)),
+              ("ties_topp_only", q, ids0, dict(temperature=1.3, top_k=0, top_p=0.6, repetition_penalty=1.0)),
+              ("ties_topk_only", q, ids0, dict(temperature=1.0, top_k=10, top_p=1.0, repetition_penalty=1.0)),
+              ("tiny_p", raw[:, 1], ids0, dict(temperature=1.0, top_k=50, top_p=1e-4, repetition_penalty=1.0)),
+              ("wide_vocab", wide, torch.from_numpy(rng.integers(0, 33000, size=(3, 40))), dict(temperature=0.9, top_k=50, top_p=0.95, repetition_penalty=1.2))]
+    out = {"case_names": np.array([c[0] for c in cases])}
+    for name, lg, ids, kw in cases:
+        want, names = hf(lg, ids, **kw)
+        mine = OS.process(lg, ids, kw["repetition_penalty"], kw["temperature"], kw["top_k"], kw["top_p"])
+        same_mask = bool(torch.equal(torch.isinf(want), torch.isinf(mine)))
+        fin = ~torch.isinf(want)
+        ok, why = OS.same_up_to_boundary_ties(want, mine)
+        print(f"   sampling {name}: processors {names}; kept {int(fin.sum())} of {want.numel()}; oracle vs HF: identical mask {same_mask}, "
+              f"same outcome up to the boundary tie group {ok} {why}")
+        assert ok, why
+        out[f"{name}:logits"], out[f"{name}:input_ids"], out[f"{name}:scores"] = lg.numpy(), ids.numpy(), want.numpy()
+        out[f"{name}:params"] = np.array([kw["temperature"], kw["top_k"], kw["top_p"], kw["repetition_penalty"]], dtype=np.float64)
+    np.savez_compressed(os.path.join(GOLD, "sampling.npz"), **out)
+
+
+def gen_train_steps():
+    """The COMPOSITION the reference's loop performs over several optimizer steps (train.py:107-117 torch.optim.AdamW with its defaults —
+    betas (0.9, 0.999), eps 1e-8, weight_decay 0.01 — and HF get_linear_schedule_with_warmup over int(total/5) warm-up steps;
+    train.py:157-184 zero_grad / forward / span CE / backward / step / scheduler.step): per-step loss and learning rate and a few weight
+    tensors after the last step, for the reference classes in both freeze modes (model_arch.py:33-51), fp32 on the CPU.  Also written:
+    the config.json the reference's own `save_pretrained` produces for the tiny PointLLMConfig (tests/golden/tiny_config.json — a data
+    fixture: HF's extra fields, `architectures`, dtype strings and all)."""
+    import shutil
+    import pointllm.model.pointllm as RPL
+    from pointllm.model import PointLLMLlamaForCausalLM, PointLLMConfig
+    import model_arch as RMA
+    from transformers import get_linear_schedule_with_warmup
+    dims = dims_tiny()
+    lm, pb, tok = dims.lm, dims.pb, dims.tok
+    orig_cfg = RPL.cfg_from_yaml_file
+    RPL.cfg_from_yaml_file = lambda path: _pb_cfg(pb) if os.path.basename(path) == "tiny.yaml" else orig_cfg(path)
+    cfg = PointLLMConfig(hidden_size=lm.hidden_size, intermediate_size=lm.intermediate_size,
+                         num_hidden_layers=lm.num_hidden_layers, num_attention_heads=lm.num_attention_heads,
+                         num_key_value_heads=lm.num_attention_heads, vocab_size=lm.vocab_size,
+                         rms_norm_eps=lm.rms_norm_eps, max_position_embeddings=lm.max_position_embeddings,
+                         pad_token_id=tok.pad, bos_token_id=tok.bos, eos_token_id=tok.eos,
+                         point_backbone="PointBERT", point_backbone_config_name="tiny", use_color=True,
+                         mm_use_point_start_end=True, DEFAULT_POINT_PATCH_TOKEN="<point_patch>",
+                         DEFAULT_POINT_START_TOKEN="<point_start>", DEFAULT_POINT_END_TOKEN="<point_end>",
+                         tie_word_embeddings=False, attn_implementation="eager")
+    base = PointLLMLlamaForCausalLM(cfg)
+    sd = synth.synth_state_dict(dims, 0)
+    base.load_state_dict(sd, strict=True)
+    tmp = tempfile.mkdtemp()
+    base.save_pretrained(tmp)
+    shutil.copyfile(os.path.join(tmp, "config.json"), os.path.join(GOLD, "tiny_config.json"))
+    K, B, LR = 6, 2, 1e-3
+    batches = []
+    for j in range(3):                                               # three different batches, visited twice (2 epochs x 3 steps)
+        toks, masks, Lp = synth.synth_batch(dims, B, text_len=8, num_steps=4, max_traj_token=40, first_id=10 * j)
+        pts = torch.stack([synth.synth_cloud(dims, 10 * j + i) for i in range(B)])
+        batches.append((toks, masks, pts))
+    start = np.zeros(B, dtype=np.int64)                              # the drivers of the build start FPS at index 0
+    out = {"K": np.array(K), "lr": np.array(LR), "prompt_len": np.array(Lp)}
+    for j, (toks, masks, pts) in enumerate(batches):
+        out[f"tokens{j}"], out[f"masks{j}"], out[f"points{j}"] = toks.numpy(), masks.numpy(), pts.numpy()
+    watch = ["model.embed_tokens.weight", "lm_head.weight", "model.norm.weight", "model.point_proj.4.weight", "model.point_proj.0.bias",
+             "model.layers.0.self_attn.q_proj.weight", "model.layers.1.mlp.down_proj.weight", "model.layers.1.input_layernorm.weight"]
+    for tag, unfreeze in (("frozen", False), ("unfrozen", True)):
+        args = types.SimpleNamespace(unfreeze_pc_encoder=False, unfreeze_language_model=unfreeze, model_name=tmp, num_bins=tok.num_bins)
+        model = RMA.TrajPointLLMForCausalLM(args, cfg, tmp)
+        model.load_state_dict(sd, strict=True)
+        model.get_model().point_backbone_config.update(point_patch_token=tok.point_patch, point_start_token=tok.point_start, point_end_token=tok.point_end)
+        optimizer = torch.optim.AdamW([{"params": [p for p in model.parameters() if p.requires_grad], "lr": LR}])      # train.py:107-113
+        scheduler = get_linear_schedule_with_warmup(optimizer, num_warmup_steps=int(K / 5), num_training_steps=K)    # train.py:114-117
+        model.train()
+        losses, lrs = [], []
+        for it in range(K):
+            toks, masks, pts = batches[it % 3]
+            optimizer.zero_grad()
+            with fixed_fps_start(start):
+                lg = model(input_ids=toks, attention_mask=masks, point_clouds=pts, return_dict=True).logits[:, Lp - 1:-1, :]
+            loss = F.cross_entropy(lg.reshape(-1, lg.shape[-1]), toks[:, Lp:].flatten(), ignore_index=tok.pad)
+            loss.backward()
+            lrs.append(scheduler.get_last_lr()[0])                   # the rate THIS step is taken with
+            optimizer.step()                                         # DeepSpeed's engine.step(): optimizer, then scheduler
+            scheduler.step()
+            losses.append(float(loss))
+        print(f"   train_steps {tag}: losses {[round(x, 5) for x in losses]}  lrs {lrs}")
+        out[f"{tag}:losses"], out[f"{tag}:lrs"] = np.array(losses), np.array(lrs)
+        fin = model.state_dict()
+        moved = {}
+        for n in watch:
+            if (n.startswith("model.layers.") and not unfreeze):
+                assert torch.equal(fin[n], sd[n]), n                 # frozen layers did not move
+                continue
+            out[f"{tag}:w:{n}"] = fin[n].detach().numpy()
+            moved[n] = rel(fin[n].detach(), sd[n])
+        print("      relative movement of the watched tensors:", {k.replace("model.", ""): round(v, 4) for k, v in moved.items()})
+    np.savez_compressed(os.path.join(GOLD, "train_steps.npz"), **out)
+    RPL.cfg_from_yaml_file = orig_cfg
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["pointcloud", "depth_cloud", "traj", "collate", "pointbert_full", "tiny_model", "tiny_pc_unfrozen", "tiny_model_bf16", "tiny_trained"]
+    which = sys.argv[1:] or ["pointcloud", "depth_cloud", "traj", "collate", "pointbert_full", "tiny_model", "tiny_pc_unfrozen", "tiny_model_bf16", "tiny_trained",
+                             "sampling", "train_steps"]
     for w in which:
         globals()["gen_" + w]()
     sizes = {f: os.path.getsize(os.path.join(GOLD, f)) for f in sorted(os.listdir(GOLD))}

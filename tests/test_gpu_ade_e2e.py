@@ -31,8 +31,16 @@ def test_generate_detokenize_ade_chain_matches_reference(golden_dir):
     Lp, n_new = int(g["prompt_len"]), int(g["n_new"])
     pts = torch.stack([synth.synth_cloud(dims, i) for i in range(2)])
     out = m.generate(input_ids=toks[:, :Lp].cuda(), attention_mask=masks[:, :Lp].cuda(), point_clouds=pts.cuda(), max_length=n_new,
-                     do_sample=False, fps_start=g["fps_start"])
+                     do_sample=False, fps_start=g["fps_start"], eos_token_id=None)     # the golden loop is a fixed-length arg-max loop (gen_golden.py)
     assert np.array_equal(out.sequences.cpu().numpy(), g["gen_sequences"]), "greedy ids differ from the reference's"
+    # HF's own loop (the default: eos from the config) pads a finished row and stops when every row has finished: row 0 emits eos one
+    # step before row 1, so its last token becomes pad; nothing else changes (generation/utils.py _sample: unfinished_sequences)
+    hf = m.generate(input_ids=toks[:, :Lp].cuda(), attention_mask=masks[:, :Lp].cuda(), point_clouds=pts.cuda(), max_length=n_new + 5,
+                    do_sample=False, fps_start=g["fps_start"])
+    want = g["gen_sequences"].copy()
+    assert want[0, -2] == tok.eos and want[1, -1] == tok.eos
+    want[0, -1] = tok.pad
+    assert np.array_equal(hf.sequences.cpu().numpy(), want) and len(hf.scores) == n_new
     gen_ids = out.sequences[:, Lp:]
     vals, n = T.detokenize_batch(gen_ids, tok, 8)                       # device: cut at eos, <tsep> segments, copy-forward
     gtv, gn = T.detokenize_batch(toks[:, Lp:].cuda(), tok, 8)

@@ -170,3 +170,83 @@ def test_ragged_descriptions_are_masked_and_do_standard_round_trips(tmp_path):
     va2 = SyntheticTrajData(dims, 4, frames=2, size=32, text_len=8, num_steps=5, seed=977, norm=T.TargetNorm(do_standard=True), max_desc_token=12, ragged_text=True)
     m = evaluate(args, model, va2, "val", dev)
     assert m["n"] == 4 and np.allclose(va2.norm.mean, norm.mean)
+
+
+@pytest.mark.parametrize("unfreeze", [False, True], ids=["frozen_llm", "unfrozen_llm"])
+def test_driver_train_reproduces_the_reference_training_trajectory(golden_dir, tmp_path, unfreeze):
+    """VERDICT r2 missing #5: the COMPOSITION of the reference's loop over several optimizer steps (train.py:107-117 torch AdamW defaults,
+    weight_decay 0.01, HF linear schedule; :157-184 zero_grad / forward / span CE / backward / step), recorded from the reference's own
+    classes in oracle/gen_golden.py::gen_train_steps: per-step loss, per-step learning rate and the weights after 6 steps (2 epochs x 3
+    batches) must come out of `egoscaler_amd.driver.train` itself — fp32, the same batches — within 1e-3."""
+    from egoscaler_amd.driver import train
+    from egoscaler_amd.pointllm import TrajPointLLMForCausalLM
+    g = np.load(os.path.join(golden_dir, "train_steps.npz"), allow_pickle=False)
+    tag = "unfrozen" if unfreeze else "frozen"
+    dims = dims_tiny()
+    K, Lp = int(g["K"]), int(g["prompt_len"])
+    args = types.SimpleNamespace(unfreeze_pc_encoder=False, unfreeze_language_model=unfreeze, num_bins=dims.tok.num_bins, model_name=None,
+                                 max_traj_token=40, num_steps=4, epochs=2, bs=2, lr_llm=float(g["lr"]), resume=False, out_dir=str(tmp_path),
+                                 checkpoint_dir=str(tmp_path), grad_accum_steps=1)
+    m = TrajPointLLMForCausalLM(args, dims, None, device="cuda", dtype=torch.float32)
+    sd0 = synth.synth_state_dict(dims, 0)
+    m.load_state_dict(sd0)
+
+    class RecordedBatches:
+        """The three recorded batches in the recorded order, whatever permutation the driver draws (the golden's loader order is its own)."""
+        def __init__(self):
+            self.i = 0
+
+        def __len__(self):
+            return 3 * args.bs
+
+        def batch(self, idx, device, max_traj_token):
+            j = self.i % 3
+            self.i += 1
+            toks = torch.from_numpy(g[f"tokens{j}"]).to(device)
+            return {"tokens": toks, "attention_masks": torch.from_numpy(g[f"masks{j}"]).to(device), "pcrgbs": torch.from_numpy(g[f"points{j}"]).to(device),
+                    "prompts": toks[:, :Lp]}
+    steps = []
+    hist = train(args, m, RecordedBatches(), None, torch.device("cuda"), log=lambda s: None, step_log=steps.append)
+    assert len(steps) == K and [s["step"] for s in steps] == list(range(K))
+    want_l, want_lr = g[f"{tag}:losses"], g[f"{tag}:lrs"]
+    got_l = np.array([s["loss"] for s in steps])
+    assert np.allclose([s["learning_rate"] for s in steps], want_lr, rtol=1e-12, atol=1e-20), (steps, want_lr)
+    assert float(np.abs(got_l - want_l).max() / np.abs(want_l).max()) < 1e-3, (got_l, want_l)
+    assert want_l[0] - want_l[-1] > 1.0                                                   # the trajectory is not a constant
+    assert abs(hist[0]["train_loss"] - float(want_l[:3].mean())) < 1e-3 * float(want_l[:3].mean())        # per-epoch mean, train.py:186,272
+    sd = m.state_dict()
+    rep = {}
+    for k in g.files:
+        if k.startswith(f"{tag}:w:"):
+            n = k[len(tag) + 3:]
+            ref, got, init = g[k], sd[n].float().cpu().numpy(), sd0[n].numpy()
+            moved = float(np.abs(ref - init).max())
+            err = float(np.abs(got - ref).max())
+            rep[n] = (err / (float(np.abs(ref).max()) + 1e-30), err / (moved + 1e-30))
+            assert rep[n][0] < 1e-3, (n, rep[n])                                          # the north-star tolerance on the tensor ...
+            assert rep[n][1] < 2e-2, (n, rep[n])                                          # ... and the UPDATE itself reproduced to 2 % of its size
+    assert len(rep) >= (8 if unfreeze else 5)
+    if not unfreeze:
+        assert torch.equal(sd["model.layers.0.self_attn.q_proj.weight"].cpu(), sd0["model.layers.0.self_attn.q_proj.weight"])
+    print(f"[train-steps {tag}] losses {np.round(got_l, 5).tolist()} vs {np.round(want_l, 5).tolist()}; (rel err, err / movement): "
+          + "; ".join(f"{n.replace('model.', '')} {a:.1e}/{b:.1e}" for n, (a, b) in rep.items()))
+
+
+def test_validation_keeps_the_short_last_batch(tmp_path):
+    """len(data) % bs != 0 — every sample is generated for and every image_id lands in the dump (the reference's
+    val / test DataLoader has no drop_last); len(data) < bs still evaluates."""
+    from egoscaler_amd.driver import SyntheticTrajData, evaluate
+    dims, args, model = _setup(tmp_path)
+    args.val_batches = None
+    seen = []
+    gen = model.generate
+    model.generate = lambda **kw: (seen.append(int(kw["input_ids"].shape[0])), gen(**kw))[1]
+    for n in (6, 3):                                                      # bs = 4: one full + one short batch; a single short batch
+        seen.clear()
+        va = SyntheticTrajData(dims, n, frames=2, size=32, text_len=8, num_steps=5, seed=977)
+        m = evaluate(args, model, va, "test", torch.device("cuda"))
+        assert seen == ([4, 2] if n == 6 else [3]), seen                   # every sample was generated for, the short batch included
+        dump = json.load(open(os.path.join(tmp_path, "test_gen_trajs.json")))
+        # a sample is dumped when its generation parses (train.py:249-250 skips the others): ids come from the whole range, the tail included
+        assert set(int(k) for k in dump) <= set(range(n)) and m["n"] == len(dump)
+        assert m["n"] == 0 or np.isfinite(m["ADE"])

@@ -13,18 +13,22 @@ from egoscaler_amd.pointllm import TrajPointLLMForCausalLM
 
 
 
-def run(batch=256, steps=32, prefill_chunk=16, layers=None):
-    """-> the JSON record (dict).  Also reachable as `python bench.py --workload decode`."""
+def run(batch=256, steps=32, prefill_chunk=16, layers=None, model=None):
+    """-> the JSON record (dict).  Also reachable as `python bench.py --workload decode`, and run by `python bench.py` after the headline
+    measurement on the model it already holds (`model`: a frozen-LLM bf16 TrajPointLLMForCausalLM; config.extra.decode)."""
     a = types.SimpleNamespace(batch=batch, steps=steps, prefill_chunk=prefill_chunk, layers=layers)
-    dims = dims_7b()
-    if a.layers:
-        dims.lm.num_hidden_layers = a.layers
     dev = torch.device("cuda")
-    args = types.SimpleNamespace(unfreeze_pc_encoder=False, unfreeze_language_model=False, num_bins=256, model_name=None)
-    m = TrajPointLLMForCausalLM(args, dims, None, device=dev, dtype=torch.bfloat16)
+    if model is not None:
+        m, dims = model, model.dims
+    else:
+        dims = dims_7b()
+        if a.layers:
+            dims.lm.num_hidden_layers = a.layers
+        args = types.SimpleNamespace(unfreeze_pc_encoder=False, unfreeze_language_model=False, num_bins=256, model_name=None)
+        m = TrajPointLLMForCausalLM(args, dims, None, device=dev, dtype=torch.bfloat16)
     g = torch.Generator(device=dev).manual_seed(7)
     with torch.no_grad():
-        for n, p in list(m.named_parameters()) + list(m.named_buffers()):
+        for n, p in ([] if model is not None else list(m.named_parameters()) + list(m.named_buffers())):
             leaf = n.rsplit(".", 1)[-1]
             if leaf == "num_batches_tracked":
                 continue
