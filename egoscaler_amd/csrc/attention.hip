@@ -418,6 +418,288 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
 
 
 // =================================================================================================
+// forward, second form (round 3; the default — EGOMI_ATTN_FWD=1 selects the kernel above for A/B runs).  Same tiling, same arithmetic
+// in the same order (results are bit-identical to attn_fwd_kernel), different instruction stream.  What the .s of the first form showed
+// (hipcc, gfx950) and what changes here:
+//   * ~150 v_mov per tile-step: the per-sub-tile `continue`s / interior-vs-edge diamonds made the register allocator copy the 32x32
+//     accumulators around the joins.  Here a wave walks the block's tile loop in THREE consecutive straight-line loops — interior tiles
+//     (no mask at all), edge tiles (key-padding / causal bits applied to both sub-tiles, a dead sub-tile is simply fully masked), dead
+//     tiles (DMA share and barriers only) — every wave still executes the same number of barriers.
+//   * ~64 VALU per tile-step of 64-bit address arithmetic for the 8 LDS-DMAs: per-lane global pointers are set up once and advanced
+//     by one v_lshl_add_u64 each; only the block's last, ragged tile takes the clamped slow path.
+//   * `s_waitcnt vmcnt(0)` in front of the first V^T fragment read (the ds_read_b64_tr_b16 builtin carries no alias information), i.e.
+//     the K/V prefetch of tile t+1 had to land before P.V of tile t: the transposed reads are inline asm here, issued BEFORE the softmax
+//     arithmetic of the sub-tile they belong to (their LDS latency hides under it), waited for with an explicit lgkmcnt.
+//   * K fragments: all 16 ds_read_b128 of a tile-step are issued before the first MFMA (the compiler had paired them with lgkmcnt(0)).
+// =================================================================================================
+// LDS-DMA issued from inline asm: the compiler then knows of no asynchronous LDS writer, so it neither waits vmcnt(0) in front of the
+// ds_read_b64_tr_b16 builtin nor copies fragments around; every LDS hand-over in this kernel is explicit anyway (counted vmcnt + s_barrier).
+// lds_base: wave-uniform LDS byte address of the 1-KiB piece this instruction fills (lane i writes 16 B at lds_base + 16 i).
+// Source = wave-uniform base pointer (SGPR pair) + per-lane 32-bit byte offset: one VGPR per DMA, shared by the K and the V tile.
+__device__ __forceinline__ void dma16_asm(const void* gbase, uint32_t voff, uint32_t lds_base) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voff), "s"(gbase), "s"(lds_base) : "memory", "m0");
+}
+
+template <int HD, bool MASKED>
+__device__ __forceinline__ void fwd2_tile(const char* sK, const char* sV, const bf16x8 (&qf)[HD / 16],
+                                          f32x16 (&o)[HD / 32], float& m_run, float& l_run, const float sc2, const int lane, const int half,
+                                          const uint32_t vis0, const uint32_t vis1) {
+    constexpr int NK = HD / 16, ND = HD / 32;
+    // ---- scores: the 8 K fragments of sub-tile 0 are in flight before the first MFMA, those of sub-tile 1 are issued under sub-tile 0's chain
+    // (hipcc pairs each read with its MFMA and waits lgkmcnt(0) in between unless fenced: NK/2 reads stay in flight ahead of the chain)
+    constexpr int HK = NK / 2;
+    bf16x8 ka[HK], kb[HK];
+    f32x16 x0, x1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { x0[r] = 0.f; x1[r] = 0.f; }
+#pragma unroll
+    for (int i = 0; i < HK; ++i) ka[i] = lds_row8_t<HD>(sK, lane & 31, 2 * i + half);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < HK; ++i) {
+        kb[i] = lds_row8_t<HD>(sK, lane & 31, 2 * (HK + i) + half);
+        x0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka[i], qf[i], x0, 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < HK; ++i) {
+        ka[i] = lds_row8_t<HD>(sK, 32 + (lane & 31), 2 * i + half);
+        x0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kb[i], qf[HK + i], x0, 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < HK; ++i) {
+        kb[i] = lds_row8_t<HD>(sK, 32 + (lane & 31), 2 * (HK + i) + half);
+        x1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka[i], qf[i], x1, 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- V^T fragments of sub-tile 0 (keys 0..31 of the tile) are issued under the end of sub-tile 1's chain, consumed after the softmax arithmetic
+    bf16x8 vf[2 * ND];
+#pragma unroll
+    for (int i = 0; i < HK; ++i) {
+#pragma unroll
+        for (int j = i * (2 * ND) / HK; j < (i + 1) * (2 * ND) / HK; ++j) vf[j] = lds_tr8_t<HD>(sV, 16 * (j / ND), 32 * (j % ND), lane);
+        x1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kb[i], qf[HK + i], x1, 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- online softmax (raw scores stay in x; the scale is folded into the exp)
+    if (MASKED) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            x0[r] = (vis0 >> rowmap(r, 0)) & 1u ? x0[r] : -INFINITY;
+            x1[r] = (vis1 >> rowmap(r, 0)) & 1u ? x1[r] : -INFINITY;
+        }
+    }
+    float mloc = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, x0[r]);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, x1[r]);
+    mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64)) * sc2;                  // sc2 > 0: max commutes with the scale
+    const float m_new = fmaxf(m_run, mloc);
+    const float m_safe = m_new == -INFINITY ? 0.f : m_new;
+    const float alpha = m_run == -INFINITY ? 0.f : fast_exp2(m_run - m_safe);
+    float lsum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const float p = fast_exp2(fmaf(x0[r], sc2, -m_safe));           // exp2(-inf) = 0 for masked keys
+        x0[r] = p;
+        lsum += p;
+    }
+    // O <- alpha * O, unconditionally (32 packed multiplies; the first form's "skip when alpha == 1 for the whole wave" cost a copy of the
+    // 64 accumulator registers at its join)
+#pragma unroll
+    for (int dt = 0; dt < ND; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+    // ---- P.V of sub-tile 0, then sub-tile 1 (its fragments are read while sub-tile 0's MFMAs run)
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+        float pv8[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pv8[j] = x0[8 * st + j];
+        const bf16x8 pb = pack8(pv8);
+#pragma unroll
+        for (int dt = 0; dt < ND; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[st * ND + dt], pb, o[dt], 0, 0, 0);
+    }
+#pragma unroll
+    for (int st = 0; st < 2; ++st)
+#pragma unroll
+        for (int dt = 0; dt < ND; ++dt) vf[st * ND + dt] = lds_tr8_t<HD>(sV, 32 + 16 * st, 32 * dt, lane);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const float p = fast_exp2(fmaf(x1[r], sc2, -m_safe));
+        x1[r] = p;
+        lsum += p;
+    }
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+        float pv8[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pv8[j] = x1[8 * st + j];
+        const bf16x8 pb = pack8(pv8);
+#pragma unroll
+        for (int dt = 0; dt < ND; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[st * ND + dt], pb, o[dt], 0, 0, 0);
+    }
+    lsum += __shfl_xor(lsum, 32, 64);
+    l_run = l_run * alpha + lsum;
+    m_run = m_new;
+}
+
+template <int HD>
+__global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(AttnArgs a) {
+    constexpr int TB = 64 * 2 * HD;                                    // bytes of one 64-key K or V tile
+    constexpr int RPI = 512 / HD, CPR = HD / 8, IPW = 64 / RPI / 4;    // rows per DMA instruction, 16-B chunks per row, DMAs per wave and tile
+    extern __shared__ __attribute__((aligned(16))) char smem[];       // [2][K | V] + key mask bytes
+    char* sMask = smem + 2 * 2 * TB;
+    const int lane = threadIdx.x & 63, half = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int rank, h, b;
+    attn_block_map(a, rank, h, b);
+    const int q0 = ((a.S + 127) / 128 - 1 - rank) * 128;             // causal: longest blocks first
+    const bool wave_dead = q0 + wave * 32 >= a.S;
+    const long long row_base = (long long)b * a.S;
+    const bf16_t* Q = a.q + row_base * a.ld_qkv + h * HD;
+    const bf16_t* K = a.k + row_base * a.ld_qkv + h * HD;
+    const bf16_t* V = a.v + row_base * a.ld_qkv + h * HD;
+    const int qi = q0 + wave * 32 + (lane & 31);
+    const int qr = qi < a.S ? qi : a.S - 1;
+    int last = q0 + 127 < a.S - 1 ? q0 + 127 : a.S - 1;
+    const int ntiles = a.causal ? (last / 64 + 1) : ((a.S + 63) / 64);
+    const bool ragged = ntiles * 64 > a.S;                            // the last tile has rows beyond S-1: clamped slow path for that one
+    // per-lane DMA source offsets (bytes from K resp. V, < 2^32: S <= 4096 rows) of tile 0, rows clamped once here; advanced by 64 rows per tile
+    uint32_t koff[IPW];
+#pragma unroll
+    for (int j = 0; j < IPW; ++j) {
+        const int rl = (wave * IPW + j) * RPI + lane / CPR;
+        const int ch = (lane % CPR) ^ swz<HD>(rl);
+        const int r = rl < a.S ? rl : a.S - 1;
+        koff[j] = (uint32_t)((long long)r * a.ld_qkv + ch * 8) * 2u;
+    }
+    const uint32_t tile_stride = (uint32_t)(64 * a.ld_qkv * 2);
+    const uint32_t lds0 = (uint32_t)(uintptr_t)((lds_void_t*)smem) + wave * IPW * 1024;      // this wave's first 1-KiB piece of stage 0's K tile
+    auto dma_fast = [&](int stage) {
+        const uint32_t base = __builtin_amdgcn_readfirstlane(lds0 + stage * (2 * TB));
+#pragma unroll
+        for (int j = 0; j < IPW; ++j) dma16_asm(K, koff[j], base + j * 1024);
+#pragma unroll
+        for (int j = 0; j < IPW; ++j) dma16_asm(V, koff[j], base + TB + j * 1024);
+    };
+    auto dma_slow = [&](int stage, int row0) {                         // rows clamped to S-1 (the block's ragged last tile)
+        const uint32_t base = __builtin_amdgcn_readfirstlane(lds0 + stage * (2 * TB));
+        uint32_t off[IPW];
+#pragma unroll
+        for (int j = 0; j < IPW; ++j) {
+            const int rl = (wave * IPW + j) * RPI + lane / CPR;
+            const int ch = (lane % CPR) ^ swz<HD>(rl);
+            int r = row0 + rl;
+            r = r < a.S ? r : a.S - 1;
+            off[j] = (uint32_t)((long long)r * a.ld_qkv + ch * 8) * 2u;
+        }
+#pragma unroll
+        for (int j = 0; j < IPW; ++j) dma16_asm(K, off[j], base + j * 1024);
+#pragma unroll
+        for (int j = 0; j < IPW; ++j) dma16_asm(V, off[j], base + TB + j * 1024);
+    };
+    dma_fast(0);                                                       // tile 0 (its row clamp is in the offsets)
+#pragma unroll
+    for (int j = 0; j < IPW; ++j) koff[j] += tile_stride;
+    bf16x8 qf[HD / 16];
+#pragma unroll
+    for (int ks = 0; ks < HD / 16; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(Q + (long long)qr * a.ld_qkv + 16 * ks + 8 * half);
+    uint8_t mv[AT_MASK_IT];
+    mask_fetch(a, row_base, ntiles * 64, mv);
+#pragma unroll
+    for (int ks = 0; ks < HD / 16; ++ks) asm volatile("" :: "v"(qf[ks]));     // consumed before the loop: see attn_fwd_kernel
+    mask_commit(a, row_base, ntiles * 64, mv, sMask);
+
+    f32x16 o[HD / 32];
+#pragma unroll
+    for (int dt = 0; dt < HD / 32; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+    const float sc2 = a.scale * 1.4426950408889634f;
+
+    // tile classes of this wave along the block's loop: [0, n_int) interior, [n_int, n_live) edge, [n_live, ntiles) dead
+    const int wave_q0 = q0 + wave * 32;
+    int n_live = wave_dead ? 0 : (a.causal ? (wave_q0 + 31) / 64 + 1 : ntiles);
+    n_live = n_live < ntiles ? n_live : ntiles;
+    int n_int = a.causal ? (wave_q0 >= 63 ? (wave_q0 - 63) / 64 + 1 : 0) : ntiles;      // tiles with kv0 + 63 <= wave_q0
+    n_int = n_int < n_live ? n_int : n_live;
+    if (a.S % 64 && n_int == ntiles) n_int = ntiles - 1;               // the ragged last tile has keys >= S: edge path
+
+    auto top_of_tile = [&](int t) {                                    // prefetch tile t+1, wait for tile t, meet the block
+        if (t + 1 < ntiles) {
+            if (ragged && t + 2 == ntiles) {
+                dma_slow((t + 1) & 1, (t + 1) * 64);
+            } else {
+                dma_fast((t + 1) & 1);
+#pragma unroll
+                for (int j = 0; j < IPW; ++j) koff[j] += tile_stride;
+            }
+            if (HD == 128) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    };
+    auto end_of_tile = [&]() {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                                  // buffer (t&1) is free for the DMA of tile t+2
+    };
+    int t = 0;
+    bool carried = false;                                              // tile t has been opened (top_of_tile, kmask) by the interior loop
+    unsigned long long kmask = 0ull;
+    for (; t < n_int; ++t) {                                           // interior tiles: no mask anywhere in the body
+        top_of_tile(t);
+        kmask = __ballot(sMask[t * 64 + lane] != 0);
+        if (kmask != ~0ull) { carried = true; break; }                 // a padded key: this wave continues on the edge path
+        const char* sK = smem + (t & 1) * (2 * TB);
+        fwd2_tile<HD, false>(sK, sK + TB, qf, o, m_run, l_run, sc2, lane, half, 0u, 0u);
+        end_of_tile();
+    }
+    for (; t < n_live; ++t) {                                          // edge tiles: key-padding and causal bits on both sub-tiles
+        if (!carried) {
+            top_of_tile(t);
+            kmask = __ballot(sMask[t * 64 + lane] != 0);
+        }
+        carried = false;
+        const int kv0 = t * 64;
+        const char* sK = smem + (t & 1) * (2 * TB);
+        const uint32_t v0 = visible_bits((uint32_t)kmask, half, kv0, qi, a.causal), v1 = visible_bits((uint32_t)(kmask >> 32), half, kv0 + 32, qi, a.causal);
+        fwd2_tile<HD, true>(sK, sK + TB, qf, o, m_run, l_run, sc2, lane, half, v0, v1);
+        end_of_tile();
+    }
+    for (; t < ntiles; ++t) {                                          // dead tiles of this wave: its DMA share and the barriers
+        top_of_tile(t);
+        end_of_tile();
+    }
+    const float inv = l_run > 0.f ? 1.0f / l_run : 0.f;
+    if constexpr (HD == 128) {
+        store_rows_via_lds(smem + wave * AT_XBYTES, o, inv, a.o + row_base * a.ld_o + h * HD, a.ld_o, q0 + wave * 32, a.S, lane);
+    } else {
+        if (qi < a.S) {
+            bf16_t* orow = a.o + (row_base + qi) * a.ld_o + h * HD;
+#pragma unroll
+            for (int dt = 0; dt < HD / 32; ++dt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    u32x2 w;
+                    w[0] = (uint32_t)f2bf(o[dt][4 * g] * inv) | ((uint32_t)f2bf(o[dt][4 * g + 1] * inv) << 16);
+                    w[1] = (uint32_t)f2bf(o[dt][4 * g + 2] * inv) | ((uint32_t)f2bf(o[dt][4 * g + 3] * inv) << 16);
+                    *reinterpret_cast<u32x2*>(orow + 32 * dt + 8 * g + 4 * half) = w;
+                }
+        }
+    }
+    if (qi < a.S && half == 0 && a.lse)                                // natural-log LSE of the SCALED scores
+        a.lse[((long long)b * a.H + h) * a.S + qi] = (m_run == -INFINITY) ? INFINITY : m_run * 0.6931471805599453f + logf(l_run);
+}
+
+
+// =================================================================================================
 // backward 1/2: dQ (and delta).  Same structure as the forward (query on the lane): per 32-key sub-tile
 //   X = K.Q^T, dP^T = V.dO^T, dS^T = P^T*(dP^T - delta), dQ^T += K^T.dS^T
 // =================================================================================================
@@ -694,6 +976,17 @@ static int attn_occ() {
 }
 static bool occ_dq2() { return attn_occ() & 1; }
 
+static int g_attn_fwd_form = -1;
+static int attn_fwd_form() {
+    if (g_attn_fwd_form < 0) { const char* e = getenv("EGOMI_ATTN_FWD"); g_attn_fwd_form = e ? atoi(e) : 2; }
+    return g_attn_fwd_form;
+}
+extern "C" int egomi_attn_set_fwd_form(int form) {
+    if (form != 1 && form != 2) return EGOMI_E_BADARG;
+    g_attn_fwd_form = form;
+    return EGOMI_OK;
+}
+
 static int attn_check(const egomi_attn_desc* d, bool fwd_only = false) {
     if (!d || !d->q || !d->k || !d->v) return EGOMI_E_BADARG;
     if (d->head_dim != AT_HD && !(fwd_only && d->head_dim == 64)) return EGOMI_E_UNSUPPORTED;
@@ -722,11 +1015,20 @@ extern "C" int egomi_attn_fwd(const egomi_attn_desc* d, egomi_stream_t stream) {
     AttnArgs a = attn_args(d);
     const dim3 grid((unsigned)(((d->S + 127) / 128) * d->H * d->B));
     const size_t lds = 2 * 2 * 64 * 2 * (size_t)d->head_dim + (size_t)((d->S + 63) / 64) * 64;
+    int form = attn_fwd_form();                                        // EGOMI_ATTN_FWD=1 / egomi_attn_set_fwd_form(1): the first form (A/B runs, equality tests)
+    if ((long long)d->S * d->ld_qkv * 2 >= (1ll << 32)) form = 1;      // the second form addresses K/V rows with 32-bit byte offsets
     if (d->head_dim == 128) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        EGOMI_LAUNCH(attn_fwd_kernel<128>, grid, dim3(256), lds, (hipStream_t)stream, a);
-    } else {
+        if (form == 1) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            EGOMI_LAUNCH(attn_fwd_kernel<128>, grid, dim3(256), lds, (hipStream_t)stream, a);
+        } else {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd2_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            EGOMI_LAUNCH(attn_fwd2_kernel<128>, grid, dim3(256), lds, (hipStream_t)stream, a);
+        }
+    } else if (form == 1) {
         EGOMI_LAUNCH(attn_fwd_kernel<64>, grid, dim3(256), lds, (hipStream_t)stream, a);
+    } else {
+        EGOMI_LAUNCH(attn_fwd2_kernel<64>, grid, dim3(256), lds, (hipStream_t)stream, a);
     }
     return egomi_launch_status();
 }

@@ -510,6 +510,42 @@ def test_fused_attention_forward(ops, B, S, H, causal, masked):
     assert float((lse.cpu() - lse_ref).abs().max()) < 2e-2
 
 
+@pytest.mark.parametrize("hd", [128, 64])
+@pytest.mark.parametrize("B,S,H,causal,mask", [(2, 692, 3, True, "tail"), (1, 692, 2, True, None), (2, 513, 6, False, None), (1, 200, 2, True, "holes"),
+                                               (2, 64, 1, False, "tail"), (1, 33, 2, True, None), (1, 1, 1, True, None), (2, 300, 2, False, "holes"), (1, 1000, 1, True, "tail")])
+def test_fused_attention_forward_second_form_is_bit_identical(ops, hd, B, S, H, causal, mask):
+    """attn_fwd2_kernel (straight-line interior / edge / dead tile loops, asm LDS-DMA, early transposed reads) against attn_fwd_kernel: same
+    arithmetic in the same order -> the same bits in O and LSE, for interior tiles, diagonal tiles, ragged last tiles, key-padding at the
+    tail and in the middle of the sequence, dead waves, both head dims."""
+    import ctypes
+    from egoscaler_amd import _lib
+    L = _lib.lib()
+    qkv = rnd(B * S, 3 * H * hd, dtype=torch.bfloat16, seed=S + hd).cuda()
+    km = None
+    if mask is not None:
+        km = torch.ones(B, S, dtype=torch.uint8)
+        if mask == "tail":
+            km[-1, S - max(1, S // 5):] = 0
+        else:
+            km[0, 2:4] = 0
+            km[-1, S // 2] = 0
+        km = km.cuda()
+    res = {}
+    try:
+        for form in (1, 2):
+            assert L.egomi_attn_set_fwd_form(form) == 0
+            out = torch.full((B * S, H * hd), 7.0, dtype=torch.bfloat16, device="cuda")
+            lse = torch.full((B, H, S), 7.0, dtype=torch.float32, device="cuda")
+            ops.attn_fwd(qkv, B, S, H, hd, hd ** -0.5, out, lse, causal=causal, key_mask=km)
+            torch.cuda.synchronize()
+            res[form] = (out, lse)
+    finally:
+        L.egomi_attn_set_fwd_form(2)
+    assert torch.equal(res[1][0], res[2][0])
+    assert torch.equal(res[1][1], res[2][1])
+    assert bool(torch.isfinite(res[2][0].float()).all())
+
+
 @pytest.mark.parametrize("B,S,H,causal,masked", [(2, 513, 6, False, False), (1, 65, 2, False, True), (2, 200, 3, True, True), (1, 1, 1, False, False)])
 def test_fused_attention_forward_hd64(ops, B, S, H, causal, masked):
     """head_dim 64 instance of the forward kernel (PointBERT blocks, point_encoder.py:36-57: 513 tokens, 6 heads, no mask)."""

@@ -36,6 +36,10 @@ def timeit(fn, n=10):
 
 
 f = 4.0 * B * H * S * S * hd / 2
-tf = timeit(lambda: ops.attn_fwd(qkv, B, S, H, hd, scale, out, lse, causal=True, key_mask=mask))
+from egoscaler_amd import _lib
+for form in (1, 2, 1, 2):                                  # the two forms of the forward kernel, alternated on this box
+    _lib.lib().egomi_attn_set_fwd_form(form)
+    tf = timeit(lambda: ops.attn_fwd(qkv, B, S, H, hd, scale, out, lse, causal=True, key_mask=mask))
+    print(f"B={B} S={S}: fwd form {form}: {tf*1e3:7.1f} us {f/tf/1e9:7.1f} TFLOP/s")
 tb = timeit(lambda: ops.attn_bwd(qkv, out, lse, dout, dqkv, delta, B, S, H, hd, scale, causal=True, key_mask=mask))
 print(f"B={B} S={S}: fwd {tf*1e3:7.1f} us {f/tf/1e9:7.1f} TFLOP/s   bwd {tb*1e3:7.1f} us {2.5*f/tb/1e9:7.1f} TFLOP/s (5 products counted)")
