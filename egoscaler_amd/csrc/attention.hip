@@ -15,6 +15,7 @@
 // which is conflict-free for both the b128 row reads and the transposed reads (T10 image (b)).
 #include "common.h"
 #include <math.h>
+#include <type_traits>
 
 #define AT_HD 128
 // raw v_exp_f32 (1 ulp, results below 2^-126 flush to 0): exp2f() expands to a 6-instruction denormal-safe sequence,
@@ -206,6 +207,9 @@ __device__ __forceinline__ void attn_block_map(const AttnArgs& a, int& rank, int
     rank = blockIdx.x / pairs;
     const int pair = blockIdx.x - rank * pairs;
     b = pair / a.H; h = pair - b * a.H;
+    // the divisions run on the VALU: hand the (uniform) results back to the scalar unit, so that every base pointer derived from them is
+    // SGPR arithmetic instead of 64-bit VGPR pairs (the kernels here sit at the 256-register line)
+    rank = __builtin_amdgcn_readfirstlane(rank); b = __builtin_amdgcn_readfirstlane(b); h = __builtin_amdgcn_readfirstlane(h);
 }
 // Key-padding mask -> LDS bytes (1 = visible).  The global loads are unconditional (index clamped) and issued together by
 // mask_fetch(); mask_commit() writes them to LDS later, after the block's other loads have been issued — a load under a
@@ -437,7 +441,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
 // lds_base: wave-uniform LDS byte address of the 1-KiB piece this instruction fills (lane i writes 16 B at lds_base + 16 i).
 // Source = wave-uniform base pointer (SGPR pair) + per-lane 32-bit byte offset: one VGPR per DMA, shared by the K and the V tile.
 __device__ __forceinline__ void dma16_asm(const void* gbase, uint32_t voff, uint32_t lds_base) {
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voff), "s"(gbase), "s"(lds_base) : "memory", "m0");
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voff), "s"(gbase), "s"(lds_base) : "memory");     // (m0 is a reserved register: hipcc re-loads it in front of each of its own uses)
 }
 
 template <int HD, bool MASKED>
@@ -829,6 +833,207 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_dq_kernel(AttnArgs a) {
 }
 
 // =================================================================================================
+// backward 1/2, second form (round 3, default; egomi_attn_set_bwd_form(1) / EGOMI_ATTN_BWD=1 select the kernels above and below for A/B runs).
+// Same tiling and arithmetic as attn_bwd_dq_kernel<2> — results are bit-identical — with the instruction-stream changes of
+// attn_fwd2_kernel: LDS-DMA from inline asm (the compiler put `s_waitcnt vmcnt(0)` in front of the K^T fragment reads of every tile, draining
+// the K/V prefetch), per-wave interior / edge / dead tile loops of straight-line code, K / V row fragments read two steps ahead of the
+// two interleaved MFMA chains, K^T fragments issued before the exponentials.
+// =================================================================================================
+template <bool MASKED>
+__device__ __forceinline__ void dq2_subtile(const char* sK, const char* sV, const int sub, const bf16x8 (&qf)[8], const bf16x8 (&dof)[8], f32x16 (&dq)[4],
+                                            const float sc2, const float lse2, const float dlt, const uint32_t vis, const int lane, const int half) {
+    f32x16 x, dp;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { x[r] = 0.f; dp[r] = 0.f; }
+    const int row = 32 * sub + (lane & 31);
+    bf16x8 kr[3], vr[3];
+    kr[0] = lds_row8(sK, row, half);     vr[0] = lds_row8(sV, row, half);
+    kr[1] = lds_row8(sK, row, 2 + half); vr[1] = lds_row8(sV, row, 2 + half);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+        if (ks + 2 < 8) {
+            kr[(ks + 2) % 3] = lds_row8(sK, row, 2 * (ks + 2) + half);
+            vr[(ks + 2) % 3] = lds_row8(sV, row, 2 * (ks + 2) + half);
+        }
+        x = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kr[ks % 3], qf[ks], x, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vr[ks % 3], dof[ks], dp, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    bf16x8 kt0[4], kt1[4];                                               // K^T fragments of the dQ products: the first half in flight under the exponentials
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) kt0[dt] = lds_tr8(sK, 32 * sub, 32 * dt, lane);
+    float ds[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        float pr = fast_exp2(fmaf(x[r], sc2, -lse2));
+        if (MASKED) pr = (vis >> rowmap(r, 0)) & 1u ? pr : 0.f;
+        ds[r] = pr * (dp[r] - dlt);
+    }
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) kt1[dt] = lds_tr8(sK, 32 * sub + 16, 32 * dt, lane);
+    {
+        const bf16x8 db = pack8(&ds[0]);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kt0[dt], db, dq[dt], 0, 0, 0);
+    }
+    {
+        const bf16x8 db = pack8(&ds[8]);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kt1[dt], db, dq[dt], 0, 0, 0);
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq2_kernel(AttnArgs a) {
+    constexpr int TB = 64 * 256;                                       // bytes of one 64-key K or V tile
+    extern __shared__ __attribute__((aligned(16))) char smem[];       // [2][K | V] + key mask bytes
+    char* sMask = smem + 2 * 2 * TB;
+    const int lane = threadIdx.x & 63, half = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int rank, h, b;
+    attn_block_map(a, rank, h, b);
+    const int q0 = ((a.S + 127) / 128 - 1 - rank) * 128;
+    const bool wave_dead = q0 + wave * 32 >= a.S;
+    const long long row_base = (long long)b * a.S;
+    const bf16_t* Q = a.q + row_base * a.ld_qkv + h * AT_HD;
+    const bf16_t* K = a.k + row_base * a.ld_qkv + h * AT_HD;
+    const bf16_t* V = a.v + row_base * a.ld_qkv + h * AT_HD;
+    const bf16_t* DO = a.dout + row_base * a.ld_o + h * AT_HD;
+    const int qi = q0 + wave * 32 + (lane & 31);
+    const int qr = qi < a.S ? qi : a.S - 1;
+    int last = q0 + 127 < a.S - 1 ? q0 + 127 : a.S - 1;
+    const int ntiles = a.causal ? (last / 64 + 1) : ((a.S + 63) / 64);
+    const bool ragged = ntiles * 64 > a.S;
+    uint32_t koff[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int rl = (wave * 4 + j) * 4 + (lane >> 4);
+        const int ch = (lane & 15) ^ (((rl & 3) << 2) | ((rl >> 2) & 3));
+        const int r = rl < a.S ? rl : a.S - 1;
+        koff[j] = (uint32_t)((long long)r * a.ld_qkv + ch * 8) * 2u;
+    }
+    const uint32_t tile_stride = (uint32_t)(64 * a.ld_qkv * 2);
+    const uint32_t lds0 = (uint32_t)(uintptr_t)((lds_void_t*)smem) + wave * 4 * 1024;
+    auto dma_fast = [&](int stage) {
+        const uint32_t base = __builtin_amdgcn_readfirstlane(lds0 + stage * (2 * TB));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dma16_asm(K, koff[j], base + j * 1024);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dma16_asm(V, koff[j], base + TB + j * 1024);
+    };
+    auto dma_slow = [&](int stage, int row0) {
+        const uint32_t base = __builtin_amdgcn_readfirstlane(lds0 + stage * (2 * TB));
+        uint32_t off[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int rl = (wave * 4 + j) * 4 + (lane >> 4);
+            const int ch = (lane & 15) ^ (((rl & 3) << 2) | ((rl >> 2) & 3));
+            int r = row0 + rl;
+            r = r < a.S ? r : a.S - 1;
+            off[j] = (uint32_t)((long long)r * a.ld_qkv + ch * 8) * 2u;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dma16_asm(K, off[j], base + j * 1024);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dma16_asm(V, off[j], base + TB + j * 1024);
+    };
+    dma_fast(0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) koff[j] += tile_stride;
+    uint8_t mv[AT_MASK_IT];
+    mask_fetch(a, row_base, ntiles * 64, mv);
+    bf16x8 qf[8], dof[8];
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+        qf[ks] = *reinterpret_cast<const bf16x8*>(Q + (long long)qr * a.ld_qkv + 16 * ks + 8 * half);
+        dof[ks] = *reinterpret_cast<const bf16x8*>(DO + (long long)qr * a.ld_o + 16 * ks + 8 * half);
+    }
+    const long long st = ((long long)b * a.H + h) * a.S + qr;
+    const float lse2 = a.lse[st] * 1.4426950408889634f;
+    float dlt = 0.f;                                                   // delta[b,h,q] = sum_d dO[q,d] * O[q,d] (see attn_bwd_dq_kernel)
+    {
+        const bf16_t* Orow = a.o + (row_base + qr) * a.ld_o + h * AT_HD;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            const bf16x8 of = *reinterpret_cast<const bf16x8*>(Orow + 16 * ks + 8 * half);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) dlt = fmaf((float)dof[ks][e], (float)of[e], dlt);
+        }
+        dlt += __shfl_xor(dlt, 32, 64);
+        if (half == 0 && qi < a.S) a.delta[st] = dlt;
+    }
+    const float sc2 = a.scale * 1.4426950408889634f;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) asm volatile("" :: "v"(qf[ks]), "v"(dof[ks]));
+    asm volatile("" :: "v"(lse2), "v"(dlt));
+    mask_commit(a, row_base, ntiles * 64, mv, sMask);
+    f32x16 dq[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dq[dt][r] = 0.f;
+
+    const int wave_q0 = q0 + wave * 32;
+    int n_live = wave_dead ? 0 : (a.causal ? (wave_q0 + 31) / 64 + 1 : ntiles);
+    n_live = n_live < ntiles ? n_live : ntiles;
+    int n_int = a.causal ? (wave_q0 >= 63 ? (wave_q0 - 63) / 64 + 1 : 0) : ntiles;
+    n_int = n_int < n_live ? n_int : n_live;
+    if (a.S % 64 && n_int == ntiles) n_int = ntiles - 1;
+
+    auto top_of_tile = [&](int t) {
+        if (t + 1 < ntiles) {
+            if (ragged && t + 2 == ntiles) {
+                dma_slow((t + 1) & 1, (t + 1) * 64);
+            } else {
+                dma_fast((t + 1) & 1);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) koff[j] += tile_stride;
+            }
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    };
+    auto end_of_tile = [&]() {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    };
+    int t = 0;
+    bool carried = false;
+    unsigned long long kmask = 0ull;
+    for (; t < n_int; ++t) {
+        top_of_tile(t);
+        kmask = __ballot(sMask[t * 64 + lane] != 0);
+        if (kmask != ~0ull) { carried = true; break; }
+        const char* sK = smem + (t & 1) * (2 * TB);
+        dq2_subtile<false>(sK, sK + TB, 0, qf, dof, dq, sc2, lse2, dlt, 0u, lane, half);
+        dq2_subtile<false>(sK, sK + TB, 1, qf, dof, dq, sc2, lse2, dlt, 0u, lane, half);
+        end_of_tile();
+    }
+    for (; t < n_live; ++t) {
+        if (!carried) {
+            top_of_tile(t);
+            kmask = __ballot(sMask[t * 64 + lane] != 0);
+        }
+        carried = false;
+        const int kv0 = t * 64;
+        const char* sK = smem + (t & 1) * (2 * TB);
+        const uint32_t v0 = visible_bits((uint32_t)kmask, half, kv0, qi, a.causal), v1 = visible_bits((uint32_t)(kmask >> 32), half, kv0 + 32, qi, a.causal);
+        dq2_subtile<true>(sK, sK + TB, 0, qf, dof, dq, sc2, lse2, dlt, v0, lane, half);
+        dq2_subtile<true>(sK, sK + TB, 1, qf, dof, dq, sc2, lse2, dlt, v1, lane, half);
+        end_of_tile();
+    }
+    for (; t < ntiles; ++t) {
+        top_of_tile(t);
+        end_of_tile();
+    }
+    store_rows_via_lds(smem + wave * AT_XBYTES, dq, a.scale, a.dq + row_base * a.ld_dqkv + h * AT_HD, a.ld_dqkv, q0 + wave * 32, a.S, lane,
+                       a.rope_cos, a.rope_sin);
+}
+
+// =================================================================================================
 // backward 2/2: dK, dV.  Key on the lane: a workgroup owns 128 keys (4 waves x 32), keeps their K and
 // V fragments and the dK^T / dV^T accumulators in registers (one wave per SIMD, 512-register file) and
 // sweeps the queries in tiles of 32 (Q, dO, LSE, delta tiles double-buffered in LDS by LDS-DMA):
@@ -966,6 +1171,234 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_dkdv_kernel(AttnArgs a) {
     store_rows_via_lds(smem + wave * AT_XBYTES, dv, 1.0f, a.dv + row_base * a.ld_dqkv + h * AT_HD, a.ld_dqkv, kb0 + wave * 32, a.S, lane);
 }
 
+// =================================================================================================
+// backward 2/2, second form (round 3, default; see attn_bwd_dq2_kernel).  Same tiling and arithmetic as attn_bwd_dkdv_kernel<2> —
+// bit-identical results — with: LDS-DMA from inline asm (Q / dO / LSE / delta tiles and the block's V rows), per-wave dead / diagonal /
+// interior / ragged tile loops of straight-line code (a causal wave used to run its dead query tiles through the masked path and add
+// zeros; a wave without a real key now only moves its DMA share), Q / dO / V row fragments read two steps ahead of the two MFMA chains,
+// the first dO^T / Q^T fragments issued before the exponentials.
+// =================================================================================================
+__device__ __forceinline__ void dma4_asm(const void* gbase, uint32_t voff, uint32_t lds_base) {       // one dword per lane
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" :: "v"(voff), "s"(gbase), "s"(lds_base) : "memory");     // (m0 is a reserved register: hipcc re-loads it in front of each of its own uses)
+}
+template <bool MASKED>
+__device__ __forceinline__ void dkdv2_tile(const char* sQ, const char* sDO, const char* sVrows, const float* sL, const float* sD, const bf16x8 (&kf)[8],
+                                           f32x16 (&dk)[4], f32x16 (&dv)[4], const float sc2, const uint32_t vis, const int lane, const int half) {
+    f32x16 x, dp;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { x[r] = 0.f; dp[r] = 0.f; }
+    const int row = lane & 31;
+    bf16x8 qr[2], dr[2], vr[2];                                          // one step ahead of the two chains (three operands: 24 registers)
+    qr[0] = lds_row8(sQ, row, half); dr[0] = lds_row8(sDO, row, half); vr[0] = lds_row8(sVrows, row, half);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+        if (ks + 1 < 8) {
+            qr[(ks + 1) & 1] = lds_row8(sQ, row, 2 * (ks + 1) + half);
+            dr[(ks + 1) & 1] = lds_row8(sDO, row, 2 * (ks + 1) + half);
+            vr[(ks + 1) & 1] = lds_row8(sVrows, row, 2 * (ks + 1) + half);
+        }
+        x = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qr[ks & 1], kf[ks], x, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dr[ks & 1], vr[ks & 1], dp, 0, 0, 0);
+    }
+    bf16x8 dot[4], qt[4];                                                // dO^T fragments of the first 16 queries: in flight under the exponentials
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) dot[dt] = lds_tr8(sDO, 0, 32 * dt, lane);
+    float pv[16], ds[16];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const f32x4 l4 = *reinterpret_cast<const f32x4*>(sL + 8 * g + 4 * half);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) pv[4 * g + e] = fast_exp2(fmaf(x[4 * g + e], sc2, -l4[e] * 1.4426950408889634f));
+    }
+    if (MASKED) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) pv[r] = (vis >> rowmap(r, 0)) & 1u ? pv[r] : 0.f;
+    }
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) qt[dt] = lds_tr8(sQ, 0, 32 * dt, lane);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const f32x4 d4 = *reinterpret_cast<const f32x4*>(sD + 8 * g + 4 * half);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ds[4 * g + e] = pv[4 * g + e] * (dp[4 * g + e] - d4[e]);
+    }
+    {
+        const bf16x8 pb = pack8(&pv[0]);
+        const bf16x8 db = pack8(&ds[0]);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dot[dt], pb, dv[dt], 0, 0, 0);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) dot[dt] = lds_tr8(sDO, 16, 32 * dt, lane);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qt[dt], db, dk[dt], 0, 0, 0);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) qt[dt] = lds_tr8(sQ, 16, 32 * dt, lane);
+    }
+    {
+        const bf16x8 pb = pack8(&pv[8]);
+        const bf16x8 db = pack8(&ds[8]);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dot[dt], pb, dv[dt], 0, 0, 0);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qt[dt], db, dk[dt], 0, 0, 0);
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkdv2_kernel(AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];       // [2] x (Q 8 KB | dO 8 KB | LSE, delta 1 KB) + the block's 128 V rows (32 KB)
+    const int lane = threadIdx.x & 63, half = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int rank, h, b;
+    attn_block_map(a, rank, h, b);
+    const int kb0 = rank * 128;
+    const long long row_base = (long long)b * a.S;
+    const bf16_t* Q = a.q + row_base * a.ld_qkv + h * AT_HD;
+    const bf16_t* K = a.k + row_base * a.ld_qkv + h * AT_HD;
+    const bf16_t* V = a.v + row_base * a.ld_qkv + h * AT_HD;
+    const bf16_t* DO = a.dout + row_base * a.ld_o + h * AT_HD;
+    const float* LSE = a.lse + ((long long)b * a.H + h) * a.S;
+    const float* DEL = a.delta + ((long long)b * a.H + h) * a.S;
+    const int kj = kb0 + wave * 32 + (lane & 31);                      // this lane's key
+    const int kr = kj < a.S ? kj : a.S - 1;
+    bool key_ok = kj < a.S;
+    if (key_ok && a.key_mask) key_ok = a.key_mask[row_base + kj] != 0;
+    const bool keys_all_ok = __all(key_ok);
+    const bool wave_dead = kb0 + wave * 32 >= a.S;                     // no real key in this wave
+    char* sVblk = smem + 2 * DKV_STAGE;
+    const uint32_t lds_smem = (uint32_t)(uintptr_t)((lds_void_t*)smem);
+    {   // the block's V rows [kb0, kb0 + 128): 8 DMAs per wave, rows clamped to S-1
+        const uint32_t base = __builtin_amdgcn_readfirstlane(lds_smem + 2 * DKV_STAGE + wave * 8 * 1024);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int rl = (wave * 8 + j) * 4 + (lane >> 4);
+            const int ch = (lane & 15) ^ (((rl & 3) << 2) | ((rl >> 2) & 3));
+            int r = kb0 + rl;
+            r = r < a.S ? r : a.S - 1;
+            dma16_asm(V, (uint32_t)((long long)r * a.ld_qkv + ch * 8) * 2u, base + j * 1024);
+        }
+    }
+    bf16x8 kf[8];
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) kf[ks] = *reinterpret_cast<const bf16x8*>(K + (long long)kr * a.ld_qkv + 16 * ks + 8 * half);
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) asm volatile("" :: "v"(kf[ks]));
+    f32x16 dk[4], dv[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dk[dt][r] = 0.f; dv[dt][r] = 0.f; }
+    const float sc2 = a.scale * 1.4426950408889634f;
+    const int nq = (a.S + 31) / 32;
+    const int qt0 = a.causal ? (kb0 / 32) : 0;
+    const bool ragged = nq * 32 > a.S;
+
+    // per-lane DMA offsets of query tile qt0 (bytes from Q / dO / LSE), advanced by 32 rows per tile; the ragged last tile is clamped
+    uint32_t qoff[2], dooff[2], loff;
+    auto offsets_for = [&](int q0, uint32_t (&qo)[2], uint32_t (&dofs)[2], uint32_t& lo) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int rl = (wave * 2 + j) * 4 + (lane >> 4);
+            const int ch = (lane & 15) ^ (((rl & 3) << 2) | ((rl >> 2) & 3));
+            int r = q0 + rl;
+            r = r < a.S ? r : a.S - 1;
+            qo[j] = (uint32_t)((long long)r * a.ld_qkv + ch * 8) * 2u;
+            dofs[j] = (uint32_t)((long long)r * a.ld_o + ch * 8) * 2u;
+        }
+        int qq = q0 + lane;
+        qq = qq < a.S ? qq : a.S - 1;
+        lo = (uint32_t)qq * 4u;
+    };
+    offsets_for(qt0 * 32, qoff, dooff, loff);
+    const uint32_t q_stride = (uint32_t)(32 * a.ld_qkv * 2), do_stride = (uint32_t)(32 * a.ld_o * 2);
+    const float* LD = (wave & 1) ? DEL : LSE;                         // waves 0/2 fetch LSE, waves 1/3 delta (64 floats each; 32 are read)
+    auto issue = [&](int stage, const uint32_t (&qo)[2], const uint32_t (&dofs)[2], const uint32_t lo) {
+        const uint32_t base = __builtin_amdgcn_readfirstlane(lds_smem + stage * DKV_STAGE + wave * 2 * 1024);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) dma16_asm(Q, qo[j], base + j * 1024);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) dma16_asm(DO, dofs[j], base + 32 * 256 + j * 1024);
+        dma4_asm(LD, lo, __builtin_amdgcn_readfirstlane(lds_smem + stage * DKV_STAGE + 2 * 32 * 256 + wave * 256));
+    };
+    auto issue_next = [&](int qt_next, int stage) {                    // tile qt_next into `stage`; offsets advance with it
+        if (ragged && qt_next == nq - 1) {
+            uint32_t qo[2], dofs[2], lo;
+            offsets_for(qt_next * 32, qo, dofs, lo);
+            issue(stage, qo, dofs, lo);
+        } else {
+            issue(stage, qoff, dooff, loff);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) { qoff[j] += q_stride; dooff[j] += do_stride; }
+            loff += 128u;
+        }
+    };
+    if (qt0 < nq) issue_next(qt0, 0);
+    // V rows (8) + first tile (5) are in flight; the loop waits for "everything but the newest tile"
+    int stg = 0;
+    auto top_of_tile = [&](int qt) {
+        if (qt + 1 < nq) {
+            issue_next(qt + 1, stg ^ 1);
+            asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    };
+    auto end_of_tile = [&]() {
+        stg ^= 1;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    };
+    const char* sVrows = sVblk + wave * 32 * 256;
+    auto run = [&](auto masked_tag, int qt) {
+        constexpr bool MASKED = decltype(masked_tag)::value;
+        const char* st = smem + stg * DKV_STAGE;
+        const float* sL = reinterpret_cast<const float*>(st + 2 * 32 * 256);
+        uint32_t vis = 0u;
+        if (MASKED) {
+            const int q0 = qt * 32;
+            const int lo = a.causal ? kj - q0 - 4 * half : 0;              // query bit c = rowmap(r, 0) visible when c >= lo ...
+            const int hi = a.S - 1 - q0 - 4 * half;                        // ... and c <= hi
+            vis = key_ok ? 0xFFFFFFFFu : 0u;
+            vis &= lo <= 0 ? 0xFFFFFFFFu : (lo >= 32 ? 0u : ~((1u << lo) - 1u));
+            vis &= hi < 0 ? 0u : (hi >= 31 ? 0xFFFFFFFFu : ((2u << hi) - 1u));
+        }
+        dkdv2_tile<MASKED>(st, st + 32 * 256, sVrows, sL, sL + 64, kf, dk, dv, sc2, vis, lane, half);
+    };
+    using T_ = std::integral_constant<bool, true>;
+    using F_ = std::integral_constant<bool, false>;
+    int qt = qt0;
+    const int diag = kb0 / 32 + wave;                                  // causal: the query tile that holds this wave's own keys
+    const int dead_end = wave_dead ? nq : (a.causal ? (diag < nq ? diag : nq) : qt0);
+    for (; qt < dead_end; ++qt) {                                      // query tiles before this wave's keys (causal) / a wave without keys
+        top_of_tile(qt);
+        end_of_tile();
+    }
+    if (a.causal && qt < nq && qt == diag) {                           // the diagonal tile
+        top_of_tile(qt);
+        run(T_{}, qt);
+        end_of_tile();
+        ++qt;
+    }
+    if (keys_all_ok) {
+        const int int_end = a.S / 32;                                  // tiles whose 32 queries all exist
+        for (; qt < int_end; ++qt) {
+            top_of_tile(qt);
+            run(F_{}, qt);
+            end_of_tile();
+        }
+    }
+    for (; qt < nq; ++qt) {                                            // padded keys in this wave and / or the ragged last tile
+        top_of_tile(qt);
+        run(T_{}, qt);
+        end_of_tile();
+    }
+    store_rows_via_lds(smem + wave * AT_XBYTES, dk, a.scale, a.dk + row_base * a.ld_dqkv + h * AT_HD, a.ld_dqkv, kb0 + wave * 32, a.S, lane,
+                       a.rope_cos, a.rope_sin);
+    store_rows_via_lds(smem + wave * AT_XBYTES, dv, 1.0f, a.dv + row_base * a.ld_dqkv + h * AT_HD, a.ld_dqkv, kb0 + wave * 32, a.S, lane);
+}
+
 // Both backward kernels run at two blocks per CU (<= 256 VGPRs: dQ 234; dK/dV 256 with its V rows in LDS) — the measured
 // lever: one wave per SIMD left every LDS / MFMA latency exposed (dQ 140 -> 97 us, dK/dV 183 -> 123 us per layer).
 // EGOMI_ATTN_OCC (A/B switch): bit 0 / bit 1 clear = one block per CU, three stages, for dQ / dKdV
@@ -984,6 +1417,16 @@ static int attn_fwd_form() {
 extern "C" int egomi_attn_set_fwd_form(int form) {
     if (form != 1 && form != 2) return EGOMI_E_BADARG;
     g_attn_fwd_form = form;
+    return EGOMI_OK;
+}
+static int g_attn_bwd_form = -1;
+static int attn_bwd_form() {
+    if (g_attn_bwd_form < 0) { const char* e = getenv("EGOMI_ATTN_BWD"); g_attn_bwd_form = e ? atoi(e) : 2; }
+    return g_attn_bwd_form;
+}
+extern "C" int egomi_attn_set_bwd_form(int form) {
+    if (form != 1 && form != 2) return EGOMI_E_BADARG;
+    g_attn_bwd_form = form;
     return EGOMI_OK;
 }
 
@@ -1047,7 +1490,11 @@ extern "C" int egomi_attn_bwd(const egomi_attn_desc* d, egomi_stream_t stream) {
     const size_t lds_q = ((occ_dq2() ? 2 : 3) * 2 * 64 * 256) + (size_t)((d->S + 63) / 64) * 64;
     const int occ = attn_occ();
     const dim3 grid((unsigned)(((d->S + 127) / 128) * d->H * d->B));
-    if (occ & 1) {
+    const bool off32 = (long long)d->S * d->ld_qkv * 2 < (1ll << 32) && (long long)d->S * d->ld_o * 2 < (1ll << 32);     // the second forms address rows with 32-bit byte offsets
+    if ((occ & 1) && attn_bwd_form() == 2 && off32) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q);
+        EGOMI_LAUNCH(attn_bwd_dq2_kernel, grid, dim3(256), lds_q, s, a);
+    } else if (occ & 1) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q);
         EGOMI_LAUNCH(attn_bwd_dq_kernel<2>, grid, dim3(256), lds_q, s, a);
     } else {
@@ -1055,7 +1502,10 @@ extern "C" int egomi_attn_bwd(const egomi_attn_desc* d, egomi_stream_t stream) {
         EGOMI_LAUNCH(attn_bwd_dq_kernel<1>, grid, dim3(256), lds_q, s, a);
     }
     const size_t lds_k = (occ & 2) ? 2 * DKV_STAGE + 128 * 256 : 3 * DKV_STAGE;
-    if (occ & 2) {
+    if ((occ & 2) && attn_bwd_form() == 2 && off32) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkdv2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_k);
+        EGOMI_LAUNCH(attn_bwd_dkdv2_kernel, grid, dim3(256), lds_k, s, a);
+    } else if (occ & 2) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkdv_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_k);
         EGOMI_LAUNCH(attn_bwd_dkdv_kernel<2>, grid, dim3(256), lds_k, s, a);
     }

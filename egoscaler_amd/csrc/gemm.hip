@@ -196,6 +196,7 @@ static int launch_generic(const egomi_gemm_desc* d, hipStream_t s) {
 }
 
 int egomi_gemm_fast_try(const egomi_gemm_desc* d, hipStream_t s);   // gemm_fast.hip; returns 1 if not applicable
+int egomi_gemm_tn_try(const egomi_gemm_desc* d, hipStream_t s);     // gemm_tn.hip (k-major operands); returns 1 if not applicable
 extern thread_local hipEvent_t egomi_time_start_, egomi_time_stop_;  // api.hip
 
 extern "C" int egomi_gemm(const egomi_gemm_desc* d, egomi_stream_t stream) {
@@ -209,6 +210,8 @@ extern "C" int egomi_gemm(const egomi_gemm_desc* d, egomi_stream_t stream) {
     if (!d->force_generic) {
         const int r = egomi_gemm_fast_try(d, s);
         if (r <= 0) return r;
+        const int r2 = egomi_gemm_tn_try(d, s);
+        if (r2 <= 0) return r2;
     } else {
         egomi_time_start_ = egomi_time_stop_ = nullptr;               // egomi_gemm_time_next: consumed by this call whatever path it takes
     }

@@ -934,8 +934,10 @@ static int tile_choice(const egomi_gemm_desc* d) {
     return (d->M >= 2048 && d->N >= 8192) ? 2 : 1;
 }
 
+extern "C" int egomi_gemm_tn_kernel_id(const egomi_gemm_desc* d);      // gemm_tn.hip: 3 when the k-major 8-phase kernel takes the product
 extern "C" int egomi_gemm_kernel_id(const egomi_gemm_desc* d) {
     if (!d) return EGOMI_E_BADARG;
+    if (!d->force_generic && !fast_applicable(d)) return egomi_gemm_tn_kernel_id(d);
     if (d->force_generic || !fast_applicable(d)) return 0;
     return tile_choice(d) == 8 ? 2 : 1;
 }

@@ -61,6 +61,9 @@ class Engine:
         self.use_fused_swiglu = os.environ.get("EGOMI_NO_FUSED_SWIGLU", "0") != "1"   # SwiGLU in the gate|up GEMM epilogue where the 256x256
                                                                                       # kernel runs (tests and A/B runs switch it off)
         self.use_tail_fuse = os.environ.get("EGOMI_NO_TAIL_FUSE", "0") != "1"         # K-sliced tail rows summed by the RMSNorm that reads them
+        # trainable decoder weights: weight gradients and data gradients on the k-major 8-phase kernel (csrc/gemm_tn.hip) — no transposed
+        # copies of dY / X per product, no resident W^T that must follow every optimizer step.  EGOMI_GEMM_TN=0: the round-1/2 route (A/B)
+        self.use_tn = os.environ.get("EGOMI_GEMM_TN", "1") != "0"
         self.pb_trainer = None
         self.defer_splice_check = False     # hipGraph capture of a whole step: the marker verdict is copied to pinned memory by the graph and
         self.pending_splice = None          # looked at by the caller after the replay (check_pending_splice) instead of inside the forward pass
@@ -101,8 +104,8 @@ class Engine:
         if self.dtype == torch.bfloat16:
             for l in range(lm.num_hidden_layers):
                 for nm in self.layer_param_names(l):
-                    if w[nm].dim() == 2:
-                        self.wT[nm] = ops.transpose(w[nm])     # trainable ones are refreshed by after_weights_update()
+                    if w[nm].dim() == 2 and not (self.use_tn and nm in self.trainable):
+                        self.wT[nm] = ops.transpose(w[nm])     # trainable ones (EGOMI_GEMM_TN=0 only) are refreshed by after_weights_update()
         # frozen layers also keep [Wq;Wk;Wv] stacked: one N=3d product fills q|k|v (1102 vs 1010 TFLOP/s measured)
         self.wqkv = {}
         if self.dtype == torch.bfloat16:
@@ -503,7 +506,12 @@ class Engine:
         wt = self.wT.get(name) if self.prepared else None
         if wt is not None:
             return ops.mm(dY, wt, out=out, residual=residual)
-        return ops.mm(dY, self.w[name], out=out, b_layout=1, residual=residual)
+        W = self.w[name]
+        if self.use_tn and self.dtype == torch.bfloat16 and (residual is None or residual is out):
+            acc = residual is not None                              # "+ residual" with residual == out is an accumulation into out
+            if ops.mm_kernel_id(dY, W, out, b_layout=1, accumulate=acc) == 3:
+                return ops.mm(dY, W, out=out, b_layout=1, accumulate=acc)         # W [N, K] read k-major: no W^T copy
+        return ops.mm(dY, W, out=out, b_layout=1, residual=residual)
 
     def _wgrad(self, name, dY, X):
         """main_grad[name] (fp32 [N,K]) += dY^T [N,M] . X [M,K].  bf16: both operands are transposed
@@ -517,7 +525,9 @@ class Engine:
         self.grad_fresh.discard(name)
         Mr, N = dY.shape
         K = X.shape[1]
-        if self.dtype == torch.bfloat16 and Mr >= 128 and N * K >= 128 * 128:
+        if self.use_tn and self.dtype == torch.bfloat16 and ops.mm_kernel_id(dY, X, g, a_layout=1, b_layout=1, accumulate=acc) == 3:
+            ops.mm(dY, X, out=g, a_layout=1, b_layout=1, accumulate=acc)          # dY^T . X with both operands as they lie in memory
+        elif self.dtype == torch.bfloat16 and Mr >= 128 and N * K >= 128 * 128:
             Mp = (Mr + 63) // 64 * 64
             dYt = ops.transpose(dY, ldo=Mp, out=self.ws.get(f"wg_dYt_{N}_{Mp}", (N, Mp), self.dtype))
             xname = f"wg_Xt_{K}_{Mp}"

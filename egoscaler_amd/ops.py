@@ -390,6 +390,19 @@ def gemm_kernel_id(M, N, K, dtype=torch.bfloat16, out_dtype=torch.bfloat16):
     return _lib.lib().egomi_gemm_kernel_id(ctypes.byref(d))
 
 
+def mm_kernel_id(a, b, out, a_layout=0, b_layout=0, accumulate=False):
+    """Which kernel egomi_gemm would run for mm(a, b, out=out, a_layout=..., b_layout=...): 0 generic, 1 / 2 the K-contiguous tuned kernels,
+    3 the k-major 8-phase kernel of csrc/gemm_tn.hip (weight gradients, data gradients against an un-transposed weight)."""
+    M, K = (a.shape if a_layout == 0 else (a.shape[1], a.shape[0]))
+    N = b.shape[0] if b_layout == 0 else b.shape[1]
+    d = GemmDesc()
+    d.A, d.B, d.C = a.data_ptr(), b.data_ptr(), out.data_ptr()
+    d.M, d.N, d.K, d.lda, d.ldb, d.ldc = M, N, K, _ld(a), _ld(b), _ld(out)
+    d.a_layout, d.b_layout, d.ab_dtype, d.c_dtype, d.batch = a_layout, b_layout, dt(a.dtype), dt(out.dtype), 1
+    d.alpha, d.accumulate = 1.0, int(accumulate)
+    return _lib.lib().egomi_gemm_kernel_id(ctypes.byref(d))
+
+
 def swiglu_bwd(dact, gate, up, dgate, dup):
     rows, cols = gate.shape
     call("egomi_swiglu_bwd", P(dact), P(gate), P(up), P(dgate), P(dup), c_i64(rows), c_i(cols), c_i64(_ld(gate)), c_i64(_ld(dact)),

@@ -206,6 +206,7 @@ int egomi_attn_bwd(const egomi_attn_desc* desc, egomi_stream_t stream);
 /* A/B switch (like the EGOMI_* environment switches): 1 = the first form of the forward kernel, 2 = the restructured one (default;
  * bit-identical results: tests/test_gpu_kernels.py).  Process-wide, not thread-safe: measurement and tests only. */
 int egomi_attn_set_fwd_form(int form);
+int egomi_attn_set_bwd_form(int form);   /* likewise for the two backward kernels */
 
 /* Consumers of EGOMI_EPI_SLABS products (single-token decode; replace splitk combine + the next elementwise kernels of
  * HF LlamaDecoderLayer.forward, modeling_llama.py:243-281, with identical rounding).  slabs: fp32 [slices][rows][cols].

@@ -594,6 +594,51 @@ def test_fused_attention_backward(ops, B, S, H, causal, masked):
         assert err <= 3e-2 * (want.abs().max().item() + 1e-9), (name, err, want.abs().max().item())
 
 
+@pytest.mark.parametrize("B,S,H,causal,mask,rope", [(2, 692, 3, True, "tail", True), (1, 692, 2, True, None, False), (1, 200, 2, True, "holes", True),
+                                                    (2, 64, 1, False, "tail", False), (1, 33, 2, True, None, True), (1, 1, 1, True, None, False),
+                                                    (2, 300, 2, False, "holes", False), (1, 1000, 1, True, "tail", True)])
+def test_fused_attention_backward_second_form_is_bit_identical(ops, B, S, H, causal, mask, rope):
+    """attn_bwd_dq2_kernel / attn_bwd_dkdv2_kernel against the first forms: the same arithmetic in the same order -> the same bits in dq, dk,
+    dv and delta (interior, diagonal, ragged and padded tiles, dead waves, with and without the inverse-RoPE epilogue)."""
+    from egoscaler_amd import _lib
+    L = _lib.lib()
+    hd = 128
+    d = H * hd
+    qkv = rnd(B * S, 3 * d, dtype=torch.bfloat16, seed=S + 11).cuda()
+    dout = rnd(B * S, d, dtype=torch.bfloat16, seed=S + 12, scale=0.1).cuda()
+    km = None
+    if mask is not None:
+        km = torch.ones(B, S, dtype=torch.uint8)
+        if mask == "tail":
+            km[-1, S - max(1, S // 5):] = 0
+        else:
+            km[0, 2:4] = 0
+            km[-1, S // 2] = 0
+        km = km.cuda()
+    out = torch.zeros(B * S, d, dtype=torch.bfloat16, device="cuda")
+    lse = torch.zeros(B, H, S, dtype=torch.float32, device="cuda")
+    ops.attn_fwd(qkv, B, S, H, hd, hd ** -0.5, out, lse, causal=causal, key_mask=km)
+    rp = None
+    if rope:
+        cos, sin = ops.rope_tables(max(S, 8), hd, 10000.0)
+        rp = (cos.cuda(), sin.cuda())
+    res = {}
+    try:
+        for form in (1, 2):
+            assert L.egomi_attn_set_bwd_form(form) == 0
+            dqkv = torch.full((B * S, 3 * d), 3.0, dtype=torch.bfloat16, device="cuda")
+            delta = torch.full((B, H, S), 3.0, dtype=torch.float32, device="cuda")
+            ops.attn_bwd(qkv, out, lse, dout, dqkv, delta, B, S, H, hd, hd ** -0.5, causal=causal, key_mask=km, rope=rp)
+            torch.cuda.synchronize()
+            res[form] = (dqkv, delta)
+    finally:
+        L.egomi_attn_set_bwd_form(2)
+    assert torch.equal(res[1][1], res[2][1])
+    for i, nm in enumerate("qkv"):
+        assert torch.equal(res[1][0][:, i * d:(i + 1) * d], res[2][0][:, i * d:(i + 1) * d]), nm
+    assert bool(torch.isfinite(res[2][0].float()).all())
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_colsum(ops, dtype):
     x = rnd(333, 517, dtype=dtype)

@@ -41,5 +41,8 @@ for form in (1, 2, 1, 2):                                  # the two forms of th
     _lib.lib().egomi_attn_set_fwd_form(form)
     tf = timeit(lambda: ops.attn_fwd(qkv, B, S, H, hd, scale, out, lse, causal=True, key_mask=mask))
     print(f"B={B} S={S}: fwd form {form}: {tf*1e3:7.1f} us {f/tf/1e9:7.1f} TFLOP/s")
-tb = timeit(lambda: ops.attn_bwd(qkv, out, lse, dout, dqkv, delta, B, S, H, hd, scale, causal=True, key_mask=mask))
+for form in (1, 2, 1, 2):
+    _lib.lib().egomi_attn_set_bwd_form(form)
+    tb = timeit(lambda: ops.attn_bwd(qkv, out, lse, dout, dqkv, delta, B, S, H, hd, scale, causal=True, key_mask=mask))
+    print(f"B={B} S={S}: bwd form {form}: {tb*1e3:7.1f} us {2.5*f/tb/1e9:7.1f} TFLOP/s")
 print(f"B={B} S={S}: fwd {tf*1e3:7.1f} us {f/tf/1e9:7.1f} TFLOP/s   bwd {tb*1e3:7.1f} us {2.5*f/tb/1e9:7.1f} TFLOP/s (5 products counted)")
