@@ -141,43 +141,23 @@ void gemm_bf16_8phase_t_kernel(TnArgs g) {
     const uint32_t lds0 = (uint32_t)(uintptr_t)((tn_lds_void*)smem);
     const char* sm = reinterpret_cast<const char*>(smem);
 
-    // DMA of half-tile (slot) of K-tile t into buffer b.  k-major operands advance by 64 rows per K-tile, k-contiguous ones by 64
-    // elements; in the ragged last K-tile the 4-row pieces past the end come from the zero page (K % 4 == 0: a piece is never split).
+    // DMA of one half-tile (slot 0/1 = A-h0/h1, 2/3 = B-h0/h1) of the K-tile whose operand base pointer is `base` into buffer b: two 1-KiB
+    // pieces per wave.  Everything but the two per-lane offsets is scalar and set up outside (the first version of this kernel spent
+    // 75 SALU instructions per K-tile and wave on it against 19 in gemm_nt_bf16_8phase_kernel and ran at 0.91 PFLOP/s; PMC: tools/debug/tn_pmc_probe.py).
+    // `tail` (wave-uniform, rare): the K-tile is the ragged last one — 4-row pieces past the end of the reduction come from the zero page
+    // (K % 4 == 0: a piece is never split).  k-contiguous operands (K % 64 == 0 there) never take it.
+    const uint32_t wave_lds = __builtin_amdgcn_readfirstlane(lds0 + wave * 2048);
     const void* zero_page = g_tn_zero_page;
-    auto pf = [&](int b, int slot, int t) {
-        const bool isA = slot < 2;
-        const int h = slot & 1;
-        const uint32_t dst = __builtin_amdgcn_readfirstlane(lds0 + ((b * 4 + slot) * TN_HT + (wave * 2) * 512) * 2);
-        if (isA) {
-            if (TA) {
-                const bf16_t* base = g.A + (long long)t * TN_BK * g.lda;
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    const bool past = t == t_last && (wave * 2 + i) * 4 >= k_tail;    // wave-uniform
-                    if (past) tn_dma16(zero_page, (uint32_t)((lane & 15) * 16), dst + i * 1024);
-                    else tn_dma16(base, sa.voff[h][i], dst + i * 1024);
-                }
-            } else {
-                const bf16_t* base = g.A + (long long)t * TN_BK;
-#pragma unroll
-                for (int i = 0; i < 2; ++i) tn_dma16(base, sa.voff[h][i], dst + i * 1024);
-            }
-        } else {
-            if (TB) {
-                const bf16_t* base = g.B + (long long)t * TN_BK * g.ldb;
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    const bool past = t == t_last && (wave * 2 + i) * 4 >= k_tail;
-                    if (past) tn_dma16(zero_page, (uint32_t)((lane & 15) * 16), dst + i * 1024);
-                    else tn_dma16(base, sb.voff[h][i], dst + i * 1024);
-                }
-            } else {
-                const bf16_t* base = g.B + (long long)t * TN_BK;
-#pragma unroll
-                for (int i = 0; i < 2; ++i) tn_dma16(base, sb.voff[h][i], dst + i * 1024);
-            }
-        }
-    };
+    const uint32_t zoff = (uint32_t)((lane & 15) * 16);
+    const bool ragged = k_tail != TN_BK;
+    const long long strideA = TA ? (long long)TN_BK * g.lda : TN_BK, strideB = TB ? (long long)TN_BK * g.ldb : TN_BK;      // elements per K-tile
+#define TN_PF(b, slot, base, off, tail) { \
+        const uint32_t dst_ = wave_lds + ((b) * 4 + (slot)) * (TN_HT * 2); \
+        if (!(tail)) { tn_dma16(base, (off)[0], dst_); tn_dma16(base, (off)[1], dst_ + 1024); } \
+        else { \
+            if ((wave * 2) * 4 >= k_tail) tn_dma16(zero_page, zoff, dst_); else tn_dma16(base, (off)[0], dst_); \
+            if ((wave * 2 + 1) * 4 >= k_tail) tn_dma16(zero_page, zoff, dst_ + 1024); else tn_dma16(base, (off)[1], dst_ + 1024); \
+        } }
 
     bf16x8 fa[2][4], fb0[2][2], fb1[2][2];
 #define TN_HTADDR(b, slot) (sm + ((b) * 4 + (slot)) * (TN_HT * 2))
@@ -191,29 +171,53 @@ void gemm_bf16_8phase_t_kernel(TnArgs g) {
     // B-h0's reads are retired before the ph1 barrier (its slot is refilled in ph2): the A reads issued behind them number 8 (ds_read_b128)
     // or 16 (tr reads; lgkmcnt holds 15 at most)
 #define TN_WAIT_B0 if (TA) asm volatile("s_waitcnt lgkmcnt(15)" ::: "memory"); else asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
-#define TN_TILE(b, tt) { \
+    // one K-tile from buffer b: pA1 = base of A's K-tile t+1, pA2 / pB2 = bases of K-tile t+2 (clamped to the last tile by the caller: DMAs past the
+    // end re-load it into buffers nobody reads any more, which keeps the vmcnt arithmetic constant); tl1 / tl2: that tile is the ragged last one
+#define TN_TILE_P(b, pA1, pA2, pB2, tl1, tl2) { \
+        /* ph1 */ TN_LDB(fb0, b, 0) __builtin_amdgcn_sched_barrier(0); TN_LDA(b, 0) TN_PF((b) ^ 1, 1, pA1, sa.voff[1], TA && (tl1)) TN_WAIT_B0 TN_BAR TN_MMA(0, fb0, 0) TN_BAR \
+        /* ph2 */ TN_LDB(fb1, b, 1) TN_PF(b, 2, pB2, sb.voff[0], TB && (tl2)) TN_BAR TN_MMA(0, fb1, 1) TN_BAR \
+        /* ph3 */ TN_LDA(b, 1) TN_PF(b, 0, pA2, sa.voff[0], TA && (tl2)) TN_BAR TN_MMA(1, fb1, 1) TN_BAR \
+        /* ph4 */ TN_PF(b, 3, pB2, sb.voff[1], TB && (tl2)) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); TN_BAR TN_MMA(1, fb0, 0) TN_BAR \
+    }
+#define TN_TILE_TAIL(b, tt) { \
         const int t1 = (tt) + 1 < t_last ? (tt) + 1 : t_last, t2 = (tt) + 2 < t_last ? (tt) + 2 : t_last; \
-        /* ph1 */ TN_LDB(fb0, b, 0) __builtin_amdgcn_sched_barrier(0); TN_LDA(b, 0) pf((b) ^ 1, 1, t1); TN_WAIT_B0 TN_BAR TN_MMA(0, fb0, 0) TN_BAR \
-        /* ph2 */ TN_LDB(fb1, b, 1) pf(b, 2, t2); TN_BAR TN_MMA(0, fb1, 1) TN_BAR \
-        /* ph3 */ TN_LDA(b, 1) pf(b, 0, t2); TN_BAR TN_MMA(1, fb1, 1) TN_BAR \
-        /* ph4 */ pf(b, 3, t2); asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); TN_BAR TN_MMA(1, fb0, 0) TN_BAR \
+        const bf16_t* pA1 = g.A + (long long)t1 * strideA; \
+        const bf16_t* pA2 = g.A + (long long)t2 * strideA; \
+        const bf16_t* pB2 = g.B + (long long)t2 * strideB; \
+        const bool tl1 = ragged && t1 == t_last, tl2 = ragged && t2 == t_last; \
+        TN_TILE_P(b, pA1, pA2, pB2, tl1, tl2) \
     }
 
     // ---- prologue: K-tile 0 complete, three half-tiles of the next one in flight
     {
         const int t1 = 1 < t_last ? 1 : t_last;
-        pf(0, 2, 0); pf(0, 0, 0); pf(0, 3, 0); pf(0, 1, 0);
-        pf(1, 2, t1); pf(1, 0, t1); pf(1, 3, t1);
+        const bf16_t* pA1 = g.A + (long long)t1 * strideA;
+        const bf16_t* pB1 = g.B + (long long)t1 * strideB;
+        const bool tl0 = ragged && t_last == 0, tl1 = ragged && t1 == t_last;
+        TN_PF(0, 2, g.B, sb.voff[0], TB && tl0) TN_PF(0, 0, g.A, sa.voff[0], TA && tl0) TN_PF(0, 3, g.B, sb.voff[1], TB && tl0) TN_PF(0, 1, g.A, sa.voff[1], TA && tl0)
+        TN_PF(1, 2, pB1, sb.voff[0], TB && tl1) TN_PF(1, 0, pA1, sa.voff[0], TA && tl1) TN_PF(1, 3, pB1, sb.voff[1], TB && tl1)
         asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         TN_BAR
     }
     if (wr == 1) { TN_BAR }                                                        // second wave group runs one barrier behind
+    // main loop: K-tiles whose two prefetch targets are whole tiles inside the reduction — running base pointers, no clamp, no tail logic in
+    // the instruction stream; the last three or four tiles (where the clamp and the ragged K-tile matter) run the general form
     int t = 0;
-    for (; t + 1 < nt; t += 2) {
-        TN_TILE(0, t)
-        TN_TILE(1, t + 1)
+    const int nt_main = (nt - 3 > 0 ? nt - 3 : 0) & ~1;
+    {
+        const bf16_t* pa = g.A;
+        const bf16_t* pb = g.B;
+        for (; t < nt_main; t += 2) {
+            TN_TILE_P(0, pa + strideA, pa + 2 * strideA, pb + 2 * strideB, false, false)
+            TN_TILE_P(1, pa + 2 * strideA, pa + 3 * strideA, pb + 3 * strideB, false, false)
+            pa += 2 * strideA; pb += 2 * strideB;
+        }
     }
-    if (t < nt) TN_TILE(0, t)
+    for (; t + 1 < nt; t += 2) {
+        TN_TILE_TAIL(0, t)
+        TN_TILE_TAIL(1, t + 1)
+    }
+    if (t < nt) TN_TILE_TAIL(0, t)
     if (wr == 0) { TN_BAR }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                               // the tail's redundant DMAs drain before the block ends
     __builtin_amdgcn_s_barrier();
