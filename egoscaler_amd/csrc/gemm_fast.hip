@@ -295,6 +295,102 @@ void gemm_nt_bf16_kernel(FastArgs g) {
 }
 
 // =================================================================================================
+// M <= 256 projections of the cached decode step (BASELINE.json configs[4], bs = 256: q|k|v, o_proj, gate|up, down_proj, lm_head against the
+// KV-cached token; HF LlamaAttention / LlamaMLP forward, modeling_llama.py:243-281,174-176).  One block owns ALL 256 rows x 128 columns, 8 waves
+// as 4 (M) x 2 (N) with the 64 x 64 accumulator layout of gemm_nt_bf16_kernel (same epilogue, same split-K slabs and consumers), and walks K in
+// 64-deep steps through a THREE-stage LDS ring (48 KB per stage: 32 KB of activations, 16 KB of weights): the DMA of step t+2 is issued right
+// after the single barrier of step t, two steps stay in flight across it (counted vmcnt, raw s_barrier).  Why this shape:
+// the fill traffic of a BN-wide tile is W (1 + 256 / BN) — the 128 x 128 kernel re-reads the 2-MB activation once per 128 x 128 tile AND keeps only
+// one K-step in flight behind a vmcnt(0) barrier (0.67 us per K-step with one block per CU); here a K-step is 32 MFMAs per wave (512 cycles) against
+// 48 KB of fill (768 cycles at 64 B/clk), and the weights cross HBM exactly once.
+// =================================================================================================
+#define M256_STAGE ((256 + 128) * FT_BK)          // elements per stage
+template <typename TC>
+__global__ __launch_bounds__(512, 2)
+void gemm_nt_bf16_m256_kernel(FastArgs g) {
+    __shared__ __attribute__((aligned(16))) bf16_t smem[3 * M256_STAGE];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    const int n0 = blockIdx.x * 128;
+
+    // per-lane LDS-DMA source pointers: A 256 rows = 32 pieces of 8 rows (4 per wave), B 128 rows = 16 pieces (2 per wave)
+    const bf16_t* srcA[4];
+    const bf16_t* srcB[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = (wave * 4 + i) * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ ((r >> 1) & 7);
+        const int ra = r < g.M ? r : g.M - 1;
+        srcA[i] = g.A + (long long)ra * g.lda + chunk * 8;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = (wave * 2 + i) * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ ((r >> 1) & 7);
+        int rb = n0 + r; rb = rb < g.N ? rb : g.N - 1;
+        srcB[i] = g.B + (long long)rb * g.ldb + chunk * 8;
+    }
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    int offA[4], offB[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) offA[i] = (wm + i * 16 + (lane & 15)) * FT_BK;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) offB[i] = 256 * FT_BK + (wn + i * 16 + (lane & 15)) * FT_BK;
+    const int sw = ((lane & 15) >> 1) & 7, c0 = lane >> 4;
+
+    int nt = g.K / FT_BK, t_begin = 0;
+    if (g.splitk > 1) {
+        const int per = (nt + g.splitk - 1) / g.splitk;
+        t_begin = blockIdx.y * per;
+        nt = t_begin + per < nt ? t_begin + per : nt;
+    }
+    const int t_last = nt - 1;
+    auto issue = [&](int t, int stage) {                              // past the slice's last step the DMA re-loads it into a stage nobody reads any more
+        const int tt = t < t_last ? t : t_last;
+        bf16_t* st = smem + stage * M256_STAGE;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) glds16(srcA[i] + (long long)tt * FT_BK, st + (wave * 4 + i) * 8 * FT_BK);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) glds16(srcB[i] + (long long)tt * FT_BK, st + 256 * FT_BK + (wave * 2 + i) * 8 * FT_BK);
+    };
+    issue(t_begin, 0);
+    issue(t_begin + 1, 1);
+    int stage = 0;
+    for (int t = t_begin; t < nt; ++t) {
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");              // step t has landed (6 DMAs per step and wave; step t+1 stays in flight)
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();                                 // ... for every wave, and every wave is done with step t-1's stage
+        __builtin_amdgcn_sched_barrier(0);
+        issue(t + 2, stage >= 1 ? stage - 1 : 2);                     // (stage + 2) % 3 = the stage step t-1 used
+        const bf16_t* cS = smem + stage * M256_STAGE;
+        stage = stage == 2 ? 0 : stage + 1;
+        bf16x8 fa[2][4], fb[2][4];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fa[ks][i] = *reinterpret_cast<const bf16x8*>(cS + offA[i] + (((c0 + 4 * ks) ^ sw) << 3));
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fb[ks][i] = *reinterpret_cast<const bf16x8*>(cS + offB[i] + (((c0 + 4 * ks) ^ sw) << 3));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[ks][j], fa[ks][i], acc[j][i], 0, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // the tail's redundant DMAs drain before the block's LDS is released
+    gemm_epilogue<TC, 4>(g, acc, wm, n0 + wn, lane, g.splitk > 1 ? g.ws + (long long)blockIdx.y * g.M * g.N : nullptr, 0);
+}
+
+// =================================================================================================
 // 256x256 tile, 8 waves (2 M x 4 N, 128x64 per wave), 8 phases per pair of K-tiles.
 // Structure after cdna_hip_programming.md "The 256^2 8-phase template": all operand traffic is LDS-DMA
 // that stays in flight across raw s_barriers (counted vmcnt, never 0 in the loop), the two wave groups
@@ -944,10 +1040,28 @@ extern "C" int egomi_gemm_kernel_id(const egomi_gemm_desc* d) {
 
 static bool slabs_form_ok(const egomi_gemm_desc* d);
 static int skinny_splitk(const egomi_gemm_desc* d, int nwg);
+// 128 < M <= 256 with a long K and enough columns: the all-rows ring kernel (gemm_nt_bf16_m256_kernel).  EGOMI_GEMM_M256=0: the 128x128 kernel (A/B runs)
+static bool m256_form(const egomi_gemm_desc* d) {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("EGOMI_GEMM_M256"); on = e ? atoi(e) : 1; }
+    // N >= 8192 (q|k|v, gate|up, lm_head): measured per shape (tools/gemm_bench_decode.py, M = 256): 41 vs 44 us, 57 vs 61, 77 vs 90; the N = 4096 products
+    // (o_proj, down_proj: 32 column tiles x 8 K-slices of 8-22 steps) are dominated by per-block fixed cost and stay on the 128x128 kernel (24.7 vs 21.9 us)
+    return on && d->M > 128 && d->M <= 256 && d->N >= 8192 && d->K >= 1024;
+}
+static int m256_splitk(const egomi_gemm_desc* d) {
+    const int nwg = (d->N + 127) / 128, nt = d->K / FT_BK;
+    if (!d->workspace) return 1;
+    int sk = d->split_k > 0 ? d->split_k : (nwg > 170 ? 1 : 256 / nwg);        // one round of <= 256 blocks
+    if (sk > nt / 4) sk = nt / 4;                                              // at least 4 K-steps per slice
+    const long long per_slab = (long long)d->M * d->N * 4;
+    if ((long long)sk * per_slab > d->workspace_bytes) sk = (int)(d->workspace_bytes / per_slab);
+    if (sk > 1) { const int per = (nt + sk - 1) / sk; sk = (nt + per - 1) / per; }     // no empty slices
+    return sk > 1 ? sk : 1;
+}
 extern "C" int egomi_gemm_slab_count(const egomi_gemm_desc* d) {
     if (!d) return EGOMI_E_BADARG;
     if (d->force_generic || !fast_applicable(d) || !slabs_form_ok(d) || tile_choice(d) != 1) return 0;
-    const int sk = skinny_splitk(d, ((d->M + 127) / 128) * ((d->N + 127) / 128));
+    const int sk = m256_form(d) ? m256_splitk(d) : skinny_splitk(d, ((d->M + 127) / 128) * ((d->N + 127) / 128));
     return sk >= 2 ? sk : 0;
 }
 
@@ -969,8 +1083,26 @@ static int skinny_splitk(const egomi_gemm_desc* d, int nwg) {
     return sk > 1 ? sk : 1;
 }
 
+static int launch_m256(const egomi_gemm_desc* d, FastArgs& g, hipStream_t s) {
+    g.tiles_m = 1; g.tiles_n = (d->N + 127) / 128;
+    g.ws = (float*)d->workspace;
+    g.splitk = m256_splitk(d);
+    if (d->epilogue == EGOMI_EPI_SLABS && g.splitk < 2) return EGOMI_E_UNSUPPORTED;     // egomi_gemm_slab_count said so
+    if (d->c_dtype == EGOMI_BF16) EGOMI_LAUNCH(gemm_nt_bf16_m256_kernel<bf16_t>, dim3(g.tiles_n, g.splitk), dim3(512), 0, s, g);
+    else if (d->c_dtype == EGOMI_F32) EGOMI_LAUNCH(gemm_nt_bf16_m256_kernel<float>, dim3(g.tiles_n, g.splitk), dim3(512), 0, s, g);
+    else return EGOMI_E_UNSUPPORTED;
+    if (g.splitk > 1 && d->epilogue != EGOMI_EPI_SLABS) {                // EGOMI_EPI_SLABS: the caller's next kernel sums the slabs
+        const long long total = (long long)d->M * ((d->N + 3) / 4);
+        const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+        if (d->c_dtype == EGOMI_BF16) EGOMI_LAUNCH(splitk_reduce_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, g);
+        else EGOMI_LAUNCH(splitk_reduce_kernel<float>, dim3(grid), dim3(256), 0, s, g);
+    }
+    return egomi_launch_status();
+}
+
 template <int BM, int BN>
 static int launch_fast(const egomi_gemm_desc* d, FastArgs& g, hipStream_t s) {
+    if (BM == 128 && BN == 128 && m256_form(d)) return launch_m256(d, g, s);
     g.tiles_m = (d->M + BM - 1) / BM; g.tiles_n = (d->N + BN - 1) / BN;
     const int nwg = g.tiles_m * g.tiles_n;
     constexpr int threads = (BM / 64) * (BN / 64) * 64;

@@ -101,6 +101,41 @@ def test_padded_prompts_decode_matches_full_forward():
     assert float((lg - ref).abs().max()) <= 5e-2 * float(ref.abs().max())
 
 
+@pytest.mark.parametrize("M,N,K", [(256, 8192, 4096), (256, 12288, 4096), (200, 8200, 2112), (129, 9000, 1024), (256, 32262, 4096), (256, 22016, 4096)])
+def test_m256_ring_kernel_matches_reference(M, N, K):
+    """gemm_nt_bf16_m256_kernel (128 < M <= 256: all rows x 128 columns per block, 3-stage LDS ring; the projections of the bs = 256 decode
+    step) against the fp32 product of the same bf16 operands: plain, every epilogue form, fp32 output, explicit and planned K-splits, unsummed
+    slabs (EGOMI_EPI_SLABS) — and bit-equality with the 128x128 kernel's result where the summation order is the same (no split)."""
+    import ctypes
+    from egoscaler_amd import ops, _lib
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.randn(M, K, generator=g).bfloat16()
+    w = (torch.randn(N, K, generator=g) * 0.05).bfloat16()
+    A, W = a.cuda(), w.cuda()
+    ref = a.float() @ w.float().t()
+    tol = 2e-2
+    ws = torch.empty(128 << 20, dtype=torch.uint8, device="cuda")
+    out = ops.mm(A, W)                                                        # no workspace: unsplit
+    assert float((out.float().cpu() - ref).abs().max()) <= tol * float(ref.abs().max())
+    out_ws = ops.mm(A, W, workspace=ws)                                       # the library's split plan + combine pass
+    assert float((out_ws.float().cpu() - ref).abs().max()) <= tol * float(ref.abs().max())
+    out32 = ops.mm(A, W, out_dtype=torch.float32, workspace=ws, split_k=3)
+    assert float((out32.cpu() - ref).abs().max()) <= 2e-3 * float(ref.abs().max())
+    if N % 8 == 0:
+        bias = torch.randn(N, generator=g).bfloat16().cuda()
+        res = torch.randn(M, N, generator=g).bfloat16().cuda()
+        full = ops.mm(A, W, bias=bias, residual=res, act=ops.ACT_GELU, alpha=0.5, workspace=ws)
+        want = torch.nn.functional.gelu(0.5 * ref + bias.float().cpu()) + res.float().cpu()
+        assert float((full.float().cpu() - want).abs().max()) <= tol * float(want.abs().max())
+    if N % 4 == 0:
+        n = ops.mm_slabs(A, W, out, ws, count_only=True)
+        if n >= 2:
+            n2 = ops.mm_slabs(A, W, out, ws)
+            assert n2 == n
+            slabs = torch.frombuffer(ws.cpu().numpy().tobytes(), dtype=torch.float32)[:n * M * N].view(n, M, N)
+            assert float((slabs.sum(0) - ref).abs().max()) <= 2e-3 * float(ref.abs().max())
+
+
 @pytest.mark.parametrize("M,N,K,sk", [(256, 4096, 4096, 0), (256, 1024, 11008, 8), (64, 512, 512, 4), (300, 2018, 384, 3)])
 def test_split_k_gemm_matches_unsplit(M, N, K, sk):
     """Skinny-M products with the K range split over blocks (fp32 slabs + combine) == the unsplit kernel."""
