@@ -201,7 +201,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=8)
-    ap.add_argument("--mode", default="frozen", choices=["frozen", "unfrozen"], help="reference default flags freeze the LLM (model_arch.py:33-51)")
+    ap.add_argument("--mode", default="frozen", choices=["frozen", "unfrozen", "pc"],
+                    help="frozen: the reference's default flags (model_arch.py:33-51).  unfrozen: --unfreeze_language_model.  pc: --unfreeze_pc_encoder "
+                         "(frozen LLM, trainable PointBERT: batch-statistics BatchNorm, DropPath, backward through the point backbone)")
     ap.add_argument("--layers", type=int, default=None, help="debug only: fewer LLaMA layers (result is then marked invalid)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the legs run after the headline measurement (config.extra: decode = configs[4], "
@@ -282,7 +284,7 @@ def main():
     B, T, H, W = a.batch, 8, 224, 224
 
     def build(mode):
-        margs = types.SimpleNamespace(unfreeze_pc_encoder=False, unfreeze_language_model=(mode == "unfrozen"), num_bins=256, model_name=None)
+        margs = types.SimpleNamespace(unfreeze_pc_encoder=(mode == "pc"), unfreeze_language_model=(mode == "unfrozen"), num_bins=256, model_name=None)
         model = TrajPointLLMForCausalLM(margs, dims, None, device=dev, dtype=torch.bfloat16)
         g = torch.Generator(device=dev).manual_seed(1234)          # same weights on every rank
         with torch.no_grad():
@@ -383,7 +385,7 @@ def main():
     clips_total = a.steps * B * world
     value = clips_total / dt / world            # clips/sec/GPU ... see `value` note below
 
-    fl = flops_per_sample(dims, S, S - Lp, frozen_llm=(a.mode == "frozen"))
+    fl = flops_per_sample(dims, S, S - Lp, frozen_llm=(a.mode != "unfrozen"))
     roof = None
     if prof is not None:
         sm = prof.summary()

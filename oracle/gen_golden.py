@@ -784,6 +784,13 @@ def gen_train_steps():
     tmp = tempfile.mkdtemp()
     base.save_pretrained(tmp)
     shutil.copyfile(os.path.join(tmp, "config.json"), os.path.join(GOLD, "tiny_config.json"))
+    # ... and the whole directory as the reference's `save_pretrained` leaves it (config.json, generation_config.json, model.safetensors with HF's
+    # metadata header): what `model_arch.py:25-31` / `builder.py:16,23` read back with from_pretrained.  Data files, nothing executable.
+    hf_dir = os.path.join(GOLD, "tiny_hf_dir")
+    os.makedirs(hf_dir, exist_ok=True)
+    for f in sorted(os.listdir(tmp)):
+        shutil.copyfile(os.path.join(tmp, f), os.path.join(hf_dir, f))
+    print("   tiny_hf_dir:", {f: os.path.getsize(os.path.join(hf_dir, f)) for f in sorted(os.listdir(hf_dir))})
     K, B, LR = 6, 2, 1e-3
     batches = []
     for j in range(3):                                               # three different batches, visited twice (2 epochs x 3 steps)
