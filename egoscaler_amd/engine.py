@@ -69,6 +69,7 @@ class Engine:
         self.pending_splice = None          # looked at by the caller after the replay (check_pending_splice) instead of inside the forward pass
         self.pb_train_mode = False          # set by TrajPointLLMForCausalLM.train(): point backbone in train() mode
         self.prepared_bn_stale = False
+        self.fold_stale = False
 
     def _notify(self, name):
         if self.grad_sync is not None and name in self.trainable and name in self.main_grad:
@@ -81,10 +82,10 @@ class Engine:
             self.grad_sync.ready_flat(f"layer{l}", self.layer_flat[l])
 
     # ------------------------------------------------------------------------------------ setup
-    def prepare(self):
-        """One-time derived weights: BatchNorm (eval) folded into the mini-PointNet convs
-        (dvae.py:193-204 with running stats, model_arch.py:121-122), RoPE tables."""
-        w, pb, lm = self.w, self.dims.pb, self.dims.lm
+    def fold_batchnorm(self):
+        """BatchNorm (eval) folded into the mini-PointNet convs (dvae.py:193-204 with running stats, model_arch.py:121-122).  Its own step:
+        with a trainable point backbone the convs and the running statistics move every optimizer step, the LLM-side derived weights do not."""
+        w, pb = self.w, self.dims.pb
         pre = "model.point_backbone.encoder."
         f = {}
         for conv, bn, key in (("first_conv.0", "first_conv.1", "c1"), ("second_conv.0", "second_conv.1", "c3")):
@@ -92,12 +93,18 @@ class Engine:
             b = w[pre + conv + ".bias"].float()
             g, beta = w[pre + bn + ".weight"].float(), w[pre + bn + ".bias"].float()
             mu, var = w[pre + bn + ".running_mean"].float(), w[pre + bn + ".running_var"].float()
-            s = g / torch.sqrt(var + pb.bn_eps)
-            f[key + "_w"] = (W * s[:, None]).to(self.dtype).contiguous()
-            f[key + "_b"] = ((b - mu) * s + beta).to(self.dtype).contiguous()
+            sc = g / torch.sqrt(var + pb.bn_eps)
+            f[key + "_w"] = (W * sc[:, None]).to(self.dtype).contiguous()
+            f[key + "_b"] = ((b - mu) * sc + beta).to(self.dtype).contiguous()
         f["c2_w"] = w[pre + "first_conv.3.weight"].squeeze(-1).contiguous()
         f["c4_w"] = w[pre + "second_conv.3.weight"].squeeze(-1).contiguous()
         self.folded = f
+        self.fold_stale = False
+
+    def prepare(self):
+        """One-time derived weights: BatchNorm fold (fold_batchnorm), resident transposes / stacks of the decoder weights, RoPE tables."""
+        w, pb, lm = self.w, self.dims.pb, self.dims.lm
+        self.fold_batchnorm()
         # frozen decoder weights: keep W^T resident too, so dgrad (dX = dY.W) runs on the tuned
         # K-contiguous kernel instead of a transposing one (+13.5 GB at 7B; 288 GB HBM pays for it)
         self.wT = {}
@@ -147,8 +154,8 @@ class Engine:
         if not self.prepared:
             return
         if self.pb_trainable:
-            self.prepared = False               # BN-folded convs of the eval path follow the new backbone weights
-            return
+            self.fold_stale = True              # BN-folded convs of the eval path follow the new backbone weights: re-folded when that path next runs
+                                                # (round 2 re-ran ALL of prepare() here: 13.5 GB of decoder-weight transposes and stacks per step, `bench.py --mode pc`)
         for nm, wt in self.wT.items():
             if nm in self.trainable:
                 ops.transpose(self.w[nm], out=wt)
@@ -234,6 +241,8 @@ class Engine:
         BatchNorm (running stats) is folded into the two convs that precede a ReLU."""
         if not self.prepared:
             self.prepare()
+        if self.fold_stale:
+            self.fold_batchnorm()
         w, pb, T, ws, f = self.w, self.dims.pb, self.dtype, self.ws, self.folded
         pre = "model.point_backbone."
         h1 = ops.linear_smallk(nb2d, f["c1_w"], f["c1_b"], act=ops.ACT_RELU, out=ws.get("pn_h1", (BG * K, pb.pn_c1), T))

@@ -73,8 +73,30 @@ class PointBackboneTrainer:
         return self.eng.grad_buffer(PRE + name)
 
     def _wg(self, name, dY, X):
+        """g[N, K] += dY^T [N, R] . X [R, K].  The outputs are small (2 - 36 tiles of 128 x 128) and the reduction long (R = B*G*M = 131072 rows in the
+        mini-PointNet, B*513 in the blocks): one block per tile walked the whole reduction alone (8.7 ms for the 256 x 128 weight: `bench.py --mode pc`
+        spent 41 ms per step here).  The reduction is cut into S equal row ranges computed as ONE batched launch into fp32 partials, summed in slice
+        order (egomi_rank_sum) and added to the gradient: deterministic, ~S x the blocks."""
         g = self._g(name)
-        ops.mm(dY, X, out=g.view(g.shape[0], -1), a_layout=1, b_layout=1, accumulate=True)
+        g2 = g.view(g.shape[0], -1)
+        R, N = dY.shape
+        K = X.shape[1]
+        tiles = -(-N // 128) * -(-K // 128)
+        S = 1
+        for cand in (128, 64, 32, 16, 8, 4, 2):
+            if tiles * cand <= 1024 and R % cand == 0 and R // cand >= 256:
+                S = cand
+                break
+        if S == 1 or (N * K) % 8:
+            ops.mm(dY, X, out=g2, a_layout=1, b_layout=1, accumulate=True)
+            return
+        chunk = R // S
+        part = self.eng.ws.get(f"pbwg_part_{S}_{N}_{K}", (S, N * K), torch.float32)
+        ops.gemm_raw(dY, X, part, N, K, chunk, ops._ld(dY), ops._ld(X), K, 1, 1, batch=S,
+                     strides=(chunk * ops._ld(dY), 0, chunk * ops._ld(X), 0, N * K, 0))
+        tot = self.eng.ws.get(f"pbwg_sum_{N}_{K}", (N * K,), torch.float32)
+        ops.rank_sum(part, tot)
+        ops.add(g2.reshape(-1), tot, out=g2.reshape(-1))
 
     def _bg(self, name, dY):
         ops.colsum_(dY, self._g(name))

@@ -466,5 +466,5 @@ class TrajPointLLMForCausalLM(nn.Module):
             self.model.point_backbone.eval()
         self.engine.pb_train_mode = bool(mode) and bool(getattr(self.args, "unfreeze_pc_encoder", False))
         if self.engine.prepared_bn_stale and not self.engine.pb_train_mode:
-            self.engine.prepared, self.engine.prepared_bn_stale = False, False      # running stats moved: re-fold BN for eval
+            self.engine.fold_stale, self.engine.prepared_bn_stale = True, False     # running stats moved: re-fold BN for eval
         return self
