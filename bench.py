@@ -391,13 +391,15 @@ def main():
         sm = prof.summary()
         ach = sm["flops"] / (sm["ms"] * 1e-3) / 1e12 if sm["ms"] > 0 else 0.0
         traffic, traffic_src = None, None
-        pj = os.path.join(ROOT, "profiles", "pmc_gemm_latest.json")
-        if os.path.exists(pj):
+        import glob
+        pjs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_gemm.json")))      # the newest round's PMC record
+        pj = pjs[-1] if pjs else ""
+        if pj and os.path.exists(pj):
             try:
                 rec = json.load(open(pj))
                 traffic = rec.get("hbm_bytes_per_launch")
-                traffic_src = ("NOT measured in this run: read from profiles/pmc_gemm_latest.json = separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
-                               "passes over `bench.py --steps 1 --warmup 1` (%s)" % rec.get("recorded", "round and commit in profiles/README.md"))
+                traffic_src = ("NOT measured in this run: read from profiles/%s = separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+                               "passes over `bench.py --steps 1 --warmup 1` (%s)" % (os.path.basename(pj), rec.get("recorded", "round and commit in profiles/README.md")))
             except Exception:
                 traffic = None
         roof = {"bound": "mfma", "kernel": "gemm_nt_bf16_8phase_kernel (every launch of %d of the %d timed steps; HIP events recorded by the library on the launch "

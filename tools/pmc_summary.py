@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Summarise two rocprofv3 counter passes (FETCH_SIZE, WRITE_SIZE; collected separately, --pmc + --kernel-trace only)
-into profiles/pmc_gemm_latest.json for one kernel-name substring.
+into profiles/rNN_pmc_gemm.json (pass the round's name as the 4th argument) for one kernel-name substring.
 
   python tools/pmc_summary.py <fetch_counter_collection.csv> <write_counter_collection.csv> [kernel substring] [out.json]
 
@@ -21,7 +21,7 @@ def avg_counter(path, counter, sub):
 def main():
     f, w = sys.argv[1], sys.argv[2]
     sub = sys.argv[3] if len(sys.argv) > 3 else "gemm_nt_bf16_8phase_kernel"
-    out = sys.argv[4] if len(sys.argv) > 4 else "profiles/pmc_gemm_latest.json"
+    out = sys.argv[4] if len(sys.argv) > 4 else "profiles/rNN_pmc_gemm.json"       # bench.py reads the newest profiles/r[0-9][0-9]_pmc_gemm.json
     fk, n1 = avg_counter(f, "FETCH_SIZE", sub)
     wk, n2 = avg_counter(w, "WRITE_SIZE", sub)
     rec = {
