@@ -113,13 +113,25 @@ class Engine:
                 for nm in self.layer_param_names(l):
                     if w[nm].dim() == 2 and not (self.use_tn and nm in self.trainable):
                         self.wT[nm] = ops.transpose(w[nm])     # trainable ones (EGOMI_GEMM_TN=0 only) are refreshed by after_weights_update()
-        # frozen layers also keep [Wq;Wk;Wv] stacked: one N=3d product fills q|k|v (1102 vs 1010 TFLOP/s measured)
-        self.wqkv = {}
+        # [Wq;Wk;Wv] stacked: one N=3d product fills q|k|v (1102 vs 1010 TFLOP/s measured).  The model allocates the three side by side
+        # (model_arch.py), so the stack is a VIEW of the parameters — also for trainable layers, whose stack thereby follows every
+        # optimizer step for free; tensors that do not lie side by side (a .to() copy, foreign storage) are concatenated when frozen
+        # and stay separate products when trainable
+        self.wqkv, self.wgu_cat = {}, {}
         if self.dtype == torch.bfloat16:
             for l in range(lm.num_hidden_layers):
                 p = f"model.layers.{l}.self_attn."
-                if not any((p + f"{n}_proj.weight") in self.trainable for n in "qkv"):
-                    self.wqkv[l] = torch.cat([w[p + f"{n}_proj.weight"] for n in "qkv"], 0)
+                names = [p + f"{n}_proj.weight" for n in "qkv"]
+                v = self._side_by_side([w[n] for n in names])
+                if v is not None:
+                    self.wqkv[l] = v
+                elif not any(n in self.trainable for n in names):
+                    self.wqkv[l] = torch.cat([w[n] for n in names], 0)
+                names = [f"model.layers.{l}.mlp.{n}_proj.weight" for n in ("gate", "up")]
+                if self.use_tn and any(n in self.trainable for n in names):
+                    v = self._side_by_side([w[n] for n in names])
+                    if v is not None:
+                        self.wgu_cat[l] = v                 # plain [Wgate;Wup]: gate columns, then up columns (no SwiGLU epilogue in training-all mode)
         # ... and [Wgate;Wup] for the forward, [WqT|WkT|WvT] / [WgateT|WupT] (K-concatenated) for dgrad: one long-K product
         # per block instead of 2-3 read-modify-write passes over dX; their separate W^T copies are dropped
         # [Wgate;Wup] is stacked with its rows INTERLEAVED in blocks of 32 (ffn % 32 == 0): gate|up then come out of the product in
@@ -130,7 +142,7 @@ class Engine:
         if self.dtype == torch.bfloat16:
             for l in range(lm.num_hidden_layers):
                 pa, pm = f"model.layers.{l}.self_attn.", f"model.layers.{l}.mlp."
-                if l in self.wqkv:
+                if l in self.wqkv and not any((pa + f"{n}_proj.weight") in self.trainable for n in "qkv"):
                     self.wqkvT[l] = torch.cat([self.wT.pop(pa + f"{n}_proj.weight") for n in "qkv"], 1)
                 if not any((pm + f"{n}_proj.weight") in self.trainable for n in ("gate", "up")):
                     self.wgu[l] = self.stack_gate_up(w[pm + "gate_proj.weight"], w[pm + "up_proj.weight"])
@@ -139,6 +151,19 @@ class Engine:
         cos, sin = ops.rope_tables(lm.max_position_embeddings, lm.head_dim, lm.rope_theta)
         self.cos, self.sin = cos.to(self.device), sin.to(self.device)
         self.prepared = True
+
+    @staticmethod
+    def _side_by_side(ts):
+        """One [sum rows, cols] view over 2-D tensors that lie back to back in one allocation, else None."""
+        t0 = ts[0]
+        if any(t.dim() != 2 or not t.is_contiguous() or t.shape[1] != t0.shape[1] or t.dtype != t0.dtype for t in ts):
+            return None
+        end = t0.data_ptr()
+        for t in ts:
+            if t.data_ptr() != end or t.untyped_storage().data_ptr() != t0.untyped_storage().data_ptr():
+                return None
+            end += t.numel() * t.element_size()
+        return torch.as_strided(t0, (sum(t.shape[0] for t in ts), t0.shape[1]), (t0.shape[1], 1))
 
     def stack_gate_up(self, gate, up):
         """[Wgate;Wup] -> [2*ffn, d]; rows interleaved in blocks of 32 when ffn allows (self.gu_il), plain concatenation otherwise."""
@@ -428,8 +453,8 @@ class Engine:
                     ops.mm(h2, self.wgu[l], out=gu)
                     ops.swiglu_il(gu, act)
             else:
-                if l in self.wgu:
-                    ops.mm(h2, self.wgu[l], out=gu)
+                if l in self.wgu or l in self.wgu_cat:
+                    ops.mm(h2, self.wgu[l] if l in self.wgu else self.wgu_cat[l], out=gu)
                 else:
                     ops.mm(h2, w[p + "mlp.gate_proj.weight"], out=gu[:, :Fd])
                     ops.mm(h2, w[p + "mlp.up_proj.weight"], out=gu[:, Fd:])
@@ -515,7 +540,10 @@ class Engine:
         wt = self.wT.get(name) if self.prepared else None
         if wt is not None:
             return ops.mm(dY, wt, out=out, residual=residual)
-        W = self.w[name]
+        return self._dgrad_w(dY, self.w[name], out, residual)
+
+    def _dgrad_w(self, dY, W, out, residual=None):
+        """out = dY . W (+ residual) with W [N, K] as it lies in memory."""
         if self.use_tn and self.dtype == torch.bfloat16 and (residual is None or residual is out):
             acc = residual is not None                              # "+ residual" with residual == out is an accumulation into out
             if ops.mm_kernel_id(dY, W, out, b_layout=1, accumulate=acc) == 3:
@@ -532,6 +560,28 @@ class Engine:
         # which saves the zero pass and the read of C (26 GB each per step when every layer is trained)
         acc = name not in self.grad_fresh
         self.grad_fresh.discard(name)
+        self._wgrad_into(g, acc, dY, X)
+
+    def _wgrad_stacked(self, names, dY, X):
+        """The gradients of weights that share their input X (q|k|v, gate|up), dY [M, sum N_i] holding their output gradients side
+        by side: ONE product into the stacked view of their gradient buffers when those lie back to back in the layer's flat block
+        and agree on overwrite-vs-accumulate; the separate products otherwise."""
+        if self.use_tn and self.dtype == torch.bfloat16 and all(n in self.trainable for n in names):
+            gs = [self.grad_buffer(n) for n in names]
+            fresh = [n in self.grad_fresh for n in names]
+            g = self._side_by_side(gs) if all(f == fresh[0] for f in fresh) else None
+            if g is not None and ops.mm_kernel_id(dY, X, g, a_layout=1, b_layout=1, accumulate=not fresh[0]) == 3:
+                for n in names:
+                    self.grad_fresh.discard(n)
+                ops.mm(dY, X, out=g, a_layout=1, b_layout=1, accumulate=not fresh[0])
+                return
+        c = 0
+        for n in names:
+            N = self.w[n].shape[0]
+            self._wgrad(n, dY[:, c:c + N], X)
+            c += N
+
+    def _wgrad_into(self, g, acc, dY, X):
         Mr, N = dY.shape
         K = X.shape[1]
         if self.use_tn and self.dtype == torch.bfloat16 and ops.mm_kernel_id(dY, X, g, a_layout=1, b_layout=1, accumulate=acc) == 3:
@@ -585,11 +635,12 @@ class Engine:
                     d_h2, t_h2 = ops.mm(dgu, self.wguT[l], out=ws.get("d_h", (M, d), T), defer_tail=True)
                 else:
                     d_h2 = ops.mm(dgu, self.wguT[l], out=ws.get("d_h", (M, d), T))
+            elif self.prepared and l in self.wgu_cat:
+                d_h2 = self._dgrad_w(dgu, self.wgu_cat[l], ws.get("d_h", (M, d), T))          # one K = 2*ffn product over [Wgate;Wup] in place
             else:
                 d_h2 = self._dgrad(dgu[:, :Fd], p + "mlp.gate_proj.weight", ws.get("d_h", (M, d), T))
                 self._dgrad(dgu[:, Fd:], p + "mlp.up_proj.weight", d_h2, residual=d_h2)
-            self._wgrad(p + "mlp.gate_proj.weight", dgu[:, :Fd], lc["h2"])
-            self._wgrad(p + "mlp.up_proj.weight", dgu[:, Fd:], lc["h2"])
+            self._wgrad_stacked([p + "mlp.gate_proj.weight", p + "mlp.up_proj.weight"], dgu, lc["h2"])
             n2 = p + "post_attention_layernorm.weight"
             d_mid = ops.rmsnorm_bwd(d_h2, lc["x_mid"], w[n2], lc["rstd2"], dx_add=dx,
                                     dw=self.grad_buffer(n2) if n2 in tr else None, out=ws.get("dx_b", (M, d), T), tail=t_h2)
@@ -610,12 +661,13 @@ class Engine:
                     d_h, t_h = ops.mm(dqkv, self.wqkvT[l], out=ws.get("d_h", (M, d), T), defer_tail=True)
                 else:
                     d_h = ops.mm(dqkv, self.wqkvT[l], out=ws.get("d_h", (M, d), T))
+            elif self.prepared and l in self.wqkv and self.use_tn and T == torch.bfloat16:
+                d_h = self._dgrad_w(dqkv, self.wqkv[l], ws.get("d_h", (M, d), T))             # one K = 3d product over [Wq;Wk;Wv] in place
             else:
                 d_h = self._dgrad(dqkv[:, :d], p + "self_attn.q_proj.weight", ws.get("d_h", (M, d), T))
                 self._dgrad(dqkv[:, d:2 * d], p + "self_attn.k_proj.weight", d_h, residual=d_h)
                 self._dgrad(dqkv[:, 2 * d:], p + "self_attn.v_proj.weight", d_h, residual=d_h)
-            for i, nm in enumerate("qkv"):
-                self._wgrad(p + f"self_attn.{nm}_proj.weight", dqkv[:, i * d:(i + 1) * d], lc["h"])
+            self._wgrad_stacked([p + f"self_attn.{nm}_proj.weight" for nm in "qkv"], dqkv, lc["h"])
             n1 = p + "input_layernorm.weight"
             dx = ops.rmsnorm_bwd(d_h, lc["x_in"], w[n1], lc["rstd1"], dx_add=d_mid,
                                  dw=self.grad_buffer(n1) if n1 in tr else None, out=ws.get("dx_a", (M, d), T), tail=t_h)

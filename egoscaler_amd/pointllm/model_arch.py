@@ -196,10 +196,24 @@ class TrajPointLLMForCausalLM(nn.Module):
         dev = torch.device(device or "cuda")
         if dev.type != "cuda":
             raise RuntimeError("TrajPointLLMForCausalLM (egoscaler_amd) runs on an MI355X only; there is no CPU path")
+        # q|k|v and gate|up of a decoder layer live side by side in ONE allocation each: every Parameter keeps its own name, shape and
+        # contiguous rows (state_dict / load_state_dict / optimizers see the reference's tensors), and the engine reads [Wq;Wk;Wv] and
+        # [Wgate;Wup] as stacked operands without holding copies that would have to follow each optimizer step
+        shapes = dict(synth.param_shapes(self.dims))
+        shared = {}
+        for l in range(self.dims.lm.num_hidden_layers):
+            for grp in (tuple(f"model.layers.{l}.self_attn.{n}_proj.weight" for n in "qkv"),
+                        tuple(f"model.layers.{l}.mlp.{n}_proj.weight" for n in ("gate", "up"))):
+                if all(g in shapes and len(shapes[g]) == 2 and shapes[g][1] == shapes[grp[0]][1] for g in grp):
+                    block = torch.zeros(sum(shapes[g][0] for g in grp), shapes[grp[0]][1], dtype=dtype, device=dev)
+                    r = 0
+                    for g in grp:
+                        shared[g] = block[r:r + shapes[g][0]]
+                        r += shapes[g][0]
         for k, shape in synth.param_shapes(self.dims):
             leaf = k.rsplit(".", 1)[-1]
             is_buf = leaf in _BUFFER_LEAVES
-            t = torch.zeros(shape, dtype=torch.long if leaf == "num_batches_tracked" else dtype, device=dev)
+            t = shared[k] if k in shared else torch.zeros(shape, dtype=torch.long if leaf == "num_batches_tracked" else dtype, device=dev)
             _install(self, k, t, is_buf)
         self._anchor = torch.zeros((), device=dev, requires_grad=True)
         self.training_graph = True

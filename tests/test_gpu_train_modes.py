@@ -86,3 +86,69 @@ def test_frozen_mode_only_updates_trainable_tensors():
         changed = not torch.equal(p.detach(), before[n])
         frozen = n.startswith(("model.layers.", "model.point_backbone."))
         assert changed != frozen or (not frozen and n.endswith("embed_tokens.weight")), n
+
+
+def test_unfrozen_stacked_products_over_parameter_views():
+    """--unfreeze_language_model, bf16: q|k|v and gate|up are allocated side by side (model_arch.py), so the engine's stacked operands
+    are VIEWS of the parameters and the step runs one forward product, one data-gradient product (k-major kernel, K = 3d / 2*ffn) and one
+    weight-gradient product (into the stacked view of the fp32 gradient block) per group.  Checked against the same model run with the
+    separate products (the side-by-side detection switched off), and after an optimizer step (a view needs no refresh)."""
+    from egoscaler_amd.engine import Engine
+    from egoscaler_amd.optim import EgoAdamW
+    dims = _dims()
+    dims.lm.hidden_size, dims.lm.num_attention_heads, dims.lm.intermediate_size = 2048, 16, 2816
+    B = 8
+    toks, masks, Lp = synth.synth_batch(dims, B, text_len=60, num_steps=20, max_traj_token=160)
+    assert toks.shape[1] == 256
+    pts = torch.stack([synth.synth_cloud(dims, i) for i in range(B)])
+    start = list(range(B))
+
+    def run(stacked):
+        m = _model(dims, True, torch.bfloat16)
+        m.train()
+        eng = m.engine
+        calls = {"dgrad": 0, "wgrad": 0}
+        if not stacked:
+            eng._side_by_side = lambda ts: None
+        dg, wg = eng._dgrad_w, eng._wgrad_into
+
+        def dgrad_w(dY, W, out, residual=None):
+            calls["dgrad"] += 1
+            return dg(dY, W, out, residual)
+
+        def wgrad_into(g, acc, dY, X):
+            calls["wgrad"] += 1
+            return wg(g, acc, dY, X)
+        eng._dgrad_w, eng._wgrad_into = dgrad_w, wgrad_into
+        loss = m.loss_and_backward(toks.cuda(), masks.cuda(), pts.cuda(), Lp, dims.tok.pad, fps_start=start)
+        grads = {n: p.main_grad.clone() for n, p in m.named_parameters() if getattr(p, "main_grad", None) is not None}
+        return m, float(loss), grads, calls
+
+    m, loss_s, g_s, c_s = run(True)
+    eng, L, d = m.engine, dims.lm.num_hidden_layers, dims.lm.hidden_size
+    for l in range(L):
+        q = eng.w[f"model.layers.{l}.self_attn.q_proj.weight"]
+        assert eng.wqkv[l].data_ptr() == q.data_ptr() and eng.wqkv[l].shape == (3 * d, d)
+        assert eng.wgu_cat[l].data_ptr() == eng.w[f"model.layers.{l}.mlp.gate_proj.weight"].data_ptr()
+        assert torch.equal(eng.wqkv[l][d:2 * d], eng.w[f"model.layers.{l}.self_attn.k_proj.weight"])
+        assert torch.equal(eng.wgu_cat[l][dims.lm.intermediate_size:], eng.w[f"model.layers.{l}.mlp.up_proj.weight"])
+    _, loss_p, g_p, c_p = run(False)
+    # per layer: stacked = 4 data-gradient products (down, gate|up, o, q|k|v) against 7; weight gradients 2 (down, o) through the
+    # per-name route + 2 stacked ones that bypass it, against 7
+    assert c_s["dgrad"] == 4 * L and c_p["dgrad"] == 7 * L, (c_s, c_p)
+    assert c_p["wgrad"] - c_s["wgrad"] == 5 * L, (c_s, c_p)
+    assert abs(loss_s - loss_p) <= 2e-3 * abs(loss_p), (loss_s, loss_p)
+    assert g_s.keys() == g_p.keys()
+    for n in g_s:
+        ref = g_p[n]
+        err = float((g_s[n] - ref).abs().max())
+        assert err <= 3e-2 * float(ref.abs().max()) + 1e-7, (n, err, float(ref.abs().max()))
+    opt = EgoAdamW(m, lr=1e-3, weight_decay=0.0)
+    before = eng.wqkv[0].clone()
+    opt.step()
+    assert not torch.equal(before, eng.wqkv[0])                              # the stack IS the parameters: it moved with them
+    assert torch.equal(eng.wqkv[0][2 * d:], dict(m.named_parameters())["model.layers.0.self_attn.v_proj.weight"].data)
+    l2 = float(m.loss_and_backward(toks.cuda(), masks.cuda(), pts.cuda(), Lp, dims.tok.pad, fps_start=start))
+    assert l2 < loss_s, (loss_s, l2)
+    sd = m.state_dict()
+    assert sd["model.layers.1.self_attn.k_proj.weight"].shape == (d, d) and sd["model.layers.1.mlp.up_proj.weight"].is_contiguous()
