@@ -309,7 +309,7 @@ def main():
         model.engine.prepared = False
         model.train()
         opt = EgoAdamW(model, lr=2e-5)
-        sync = GradSync(wire_dtype=torch.bfloat16, run_single=a.force_dist) if (world > 1 or a.force_dist) else None      # large fp32 gradient buffers cross xGMI as bf16
+        sync = GradSync(wire_dtype=torch.bfloat16, run_single=a.force_dist, resident=True) if (world > 1 or a.force_dist) else None      # large fp32 gradient buffers cross xGMI as bf16
         if sync is not None:
             sync.time_exposed = True
         model.engine.grad_sync = sync

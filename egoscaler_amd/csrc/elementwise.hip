@@ -829,34 +829,102 @@ extern "C" int egomi_ce_fwd_bwd(const void* logits, int64_t ld, const int64_t* t
 // AdamW (torch.optim.AdamW semantics, reference optimizer: train.py:107-111).  fp32 master/moments;
 // optional low-precision model copy written in the same pass.
 // ------------------------------------------------------------------------------------------------
-template <typename T>
-__global__ __launch_bounds__(256) void adamw_kernel(float* p, T* p_model, const float* g, float* m, float* v, long long n, float lr, float b1,
+template <typename G> __device__ __forceinline__ float adamw_g(const G* g, long long i);
+template <> __device__ __forceinline__ float adamw_g<float>(const float* g, long long i) { return g[i]; }
+template <> __device__ __forceinline__ float adamw_g<bf16_t>(const bf16_t* g, long long i) { return bf2f(g[i]); }
+
+// one element's update.  Contraction is switched off so that the scalar and the 16-B kernel (and every alignment of the same tensor) round
+// identically: with the default -ffp-contract=fast the two loop shapes were fused into FMAs differently (1-ulp differences in master)
+__device__ __forceinline__ void adamw_elem(float& p, float& m, float& v, float g, float lr, float b1, float b2, float eps, float wd, float bc1,
+                                           float bc2_sqrt, float gscale) {
+#pragma clang fp contract(off)
+    const float gr = g * gscale;
+    float pi = p * (1.0f - lr * wd);
+    const float mi = b1 * m + (1.0f - b1) * gr;
+    const float vi = b2 * v + ((1.0f - b2) * gr) * gr;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    pi -= (lr / bc1) * (mi / denom);
+    p = pi; m = mi; v = vi;
+}
+
+template <typename T, typename G>
+__global__ __launch_bounds__(256) void adamw_kernel(float* p, T* p_model, const G* g, float* m, float* v, long long n, float lr, float b1,
                                                     float b2, float eps, float wd, float bc1, float bc2_sqrt, float gscale) {
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
-        const float gr = g[i] * gscale;
-        float pi = p[i] * (1.0f - lr * wd);
-        const float mi = b1 * m[i] + (1.0f - b1) * gr;
-        const float vi = b2 * v[i] + (1.0f - b2) * gr * gr;
-        const float denom = sqrtf(vi) / bc2_sqrt + eps;
-        pi -= (lr / bc1) * (mi / denom);
+        float pi = p[i], mi = m[i], vi = v[i];
+        adamw_elem(pi, mi, vi, adamw_g<G>(g, i), lr, b1, b2, eps, wd, bc1, bc2_sqrt, gscale);
         p[i] = pi; m[i] = mi; v[i] = vi;
         if (p_model) Cvt<T>::st(p_model + i, pi);
     }
 }
 
-extern "C" int egomi_adamw(float* master, void* model_copy, const float* grad, float* m, float* v, int64_t n, float lr, float beta1,
-                           float beta2, float eps, float weight_decay, int step, float grad_scale, int copy_dtype, egomi_stream_t stream) {
+// 16-B form: four elements per lane and access (master, m, v read and written, the gradient read, the model copy written: 30 B per
+// element at bf16 — the pass is HBM-bound).  Same arithmetic per element.  G = bf16: the gradient is read straight from the rank-summed
+// bf16 wire buffer of dp.GradSync (28 B per element, and no widening pass before it).
+template <typename T, typename G>
+__global__ __launch_bounds__(256) void adamw_vec4_kernel(float* p, T* p_model, const G* g, float* m, float* v, long long n4, float lr, float b1,
+                                                         float b2, float eps, float wd, float bc1, float bc2_sqrt, float gscale) {
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        f32x4 g4;
+        if constexpr (sizeof(G) == 4) g4 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(g) + i);
+        else {
+            const u32x2 r = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(g) + i);
+            g4[0] = __uint_as_float(r[0] << 16); g4[1] = __uint_as_float(r[0] & 0xFFFF0000u);
+            g4[2] = __uint_as_float(r[1] << 16); g4[3] = __uint_as_float(r[1] & 0xFFFF0000u);
+        }
+        f32x4 p4 = reinterpret_cast<f32x4*>(p)[i], m4 = reinterpret_cast<f32x4*>(m)[i], v4 = reinterpret_cast<f32x4*>(v)[i];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float pi = p4[j], mi = m4[j], vi = v4[j];
+            adamw_elem(pi, mi, vi, g4[j], lr, b1, b2, eps, wd, bc1, bc2_sqrt, gscale);
+            p4[j] = pi; m4[j] = mi; v4[j] = vi;
+        }
+        reinterpret_cast<f32x4*>(p)[i] = p4; reinterpret_cast<f32x4*>(m)[i] = m4; reinterpret_cast<f32x4*>(v)[i] = v4;
+        if (p_model) {
+            T o[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) Cvt<T>::st(o + j, p4[j]);
+            typedef T tx4 __attribute__((ext_vector_type(4)));
+            reinterpret_cast<tx4*>(p_model)[i] = tx4{o[0], o[1], o[2], o[3]};            // one 8-B store (bf16)
+        }
+    }
+}
+
+template <typename G>
+static int adamw_launch(float* master, void* model_copy, const G* grad, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                        float weight_decay, int step, float grad_scale, int copy_dtype, hipStream_t stream) {
     if (!master || !grad || !m || !v) return EGOMI_E_BADARG;
     if (n <= 0 || step <= 0) return EGOMI_E_SHAPE;
+    if (model_copy && copy_dtype != EGOMI_F32 && copy_dtype != EGOMI_BF16) return EGOMI_E_BADARG;
     const float bc1 = 1.0f - powf(beta1, (float)step), bc2s = sqrtf(1.0f - powf(beta2, (float)step));
+    const long long n4 = n / 4, rest = n - 4 * n4;
+    const bool vec = n4 > 0 && (((uintptr_t)master | (uintptr_t)m | (uintptr_t)v) & 15) == 0 && ((uintptr_t)grad & (4 * sizeof(G) - 1)) == 0 &&
+                     (!model_copy || (copy_dtype == EGOMI_BF16 && ((uintptr_t)model_copy & 7) == 0));
+    if (vec) {
+        EGOMI_LAUNCH((adamw_vec4_kernel<bf16_t, G>), dim3(ew_grid(n4)), dim3(256), 0, stream, master, (bf16_t*)model_copy, grad, m, v,
+                           n4, lr, beta1, beta2, eps, weight_decay, bc1, bc2s, grad_scale);
+        if (rest == 0) return egomi_launch_status();
+        master += 4 * n4; grad += 4 * n4; m += 4 * n4; v += 4 * n4; n = rest;
+        if (model_copy) model_copy = (bf16_t*)model_copy + 4 * n4;
+    }
     if (!model_copy || copy_dtype == EGOMI_F32)
-        EGOMI_LAUNCH(adamw_kernel<float>, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, master, (float*)model_copy, grad, m, v,
+        EGOMI_LAUNCH((adamw_kernel<float, G>), dim3(ew_grid(n)), dim3(256), 0, stream, master, (float*)model_copy, grad, m, v,
                            (long long)n, lr, beta1, beta2, eps, weight_decay, bc1, bc2s, grad_scale);
-    else if (copy_dtype == EGOMI_BF16)
-        EGOMI_LAUNCH(adamw_kernel<bf16_t>, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, master, (bf16_t*)model_copy, grad, m, v,
+    else
+        EGOMI_LAUNCH((adamw_kernel<bf16_t, G>), dim3(ew_grid(n)), dim3(256), 0, stream, master, (bf16_t*)model_copy, grad, m, v,
                            (long long)n, lr, beta1, beta2, eps, weight_decay, bc1, bc2s, grad_scale);
-    else return EGOMI_E_BADARG;
     return egomi_launch_status();
+}
+
+extern "C" int egomi_adamw(float* master, void* model_copy, const float* grad, float* m, float* v, int64_t n, float lr, float beta1,
+                           float beta2, float eps, float weight_decay, int step, float grad_scale, int copy_dtype, egomi_stream_t stream) {
+    return adamw_launch<float>(master, model_copy, grad, m, v, n, lr, beta1, beta2, eps, weight_decay, step, grad_scale, copy_dtype, (hipStream_t)stream);
+}
+extern "C" int egomi_adamw_g16(float* master, void* model_copy, const void* grad_bf16, float* m, float* v, int64_t n, float lr, float beta1,
+                               float beta2, float eps, float weight_decay, int step, float grad_scale, int copy_dtype, egomi_stream_t stream) {
+    return adamw_launch<bf16_t>(master, model_copy, (const bf16_t*)grad_bf16, m, v, n, lr, beta1, beta2, eps, weight_decay, step, grad_scale, copy_dtype,
+                                (hipStream_t)stream);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -1173,6 +1173,22 @@ static TailPlan plan_tail(int M, int N, int K, long long ws_bytes) {
     return best;
 }
 
+// the same plan and combine pass for the k-major kernel (gemm_tn.hip)
+void egomi_plan_tail_rows(int M, int N, int K, long long ws_bytes, int* rows, int* slices) {
+    const TailPlan tp = plan_tail(M, N, (K + FT_BK - 1) / FT_BK * FT_BK, ws_bytes);
+    *rows = tp.rows; *slices = tp.s;
+}
+int egomi_splitk_reduce_rows(void* C, int c_dtype, long long ldc, int rows, int N, const float* ws, int slices, int accumulate, hipStream_t s) {
+    FastArgs r = {};
+    r.C = C; r.ldc = ldc; r.M = rows; r.N = N; r.ws = const_cast<float*>(ws); r.splitk = slices; r.accumulate = accumulate; r.alpha = 1.0f;
+    const long long total = (long long)rows * ((N + 3) / 4);
+    const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    if (c_dtype == EGOMI_BF16) EGOMI_LAUNCH(splitk_reduce_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, r);
+    else if (c_dtype == EGOMI_F32) EGOMI_LAUNCH(splitk_reduce_kernel<float>, dim3(grid), dim3(256), 0, s, r);
+    else return EGOMI_E_UNSUPPORTED;
+    return egomi_launch_status();
+}
+
 // persistent launch: schedule in a handful of integers, everything else is derived inside the kernel.  Needs the caller's
 // workspace (4 KB of ticket words, zero on entry and left zero, then G*2 slabs of 256 KB) and an even number of K-tiles.
 static int p8_cus() {

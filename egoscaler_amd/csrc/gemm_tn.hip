@@ -29,6 +29,8 @@ struct TnArgs {
     long long lda, ldb, ldc;
     int accumulate;
     int tiles_m, tiles_n;
+    int full_tm, full_tiles, tail_s;           // ragged last round (gemm_fast.hip plan_tail): tile rows >= full_tm are cut into tail_s K-slices,
+    float* ws;                                 // whose fp32 partial sums go to ws [tail_s][M - 256 full_tm][N] (summed by splitk_reduce_kernel)
 };
 
 // 256 B of zeros for the reduction rows past the end of a ragged last K-tile (addressed from device code: no host-side symbol lookup)
@@ -110,19 +112,28 @@ void gemm_bf16_8phase_t_kernel(TnArgs g) {
     const int wr = wave >> 2, wc = wave & 3;
 
     // XCD-aware grouped tile order (as gemm_nt_bf16_8phase_kernel): 8 M-tiles x consecutive N-tiles run together on one XCD
-    int tm, tn;
-    {
-        const int nwg = g.tiles_m * g.tiles_n;
+    // whole tiles first, then the K-slices of the tail rows: the dispatcher hands blocks out in index order, so the short blocks fill the
+    // ragged last round
+    int tm, tn, kz = 0, ksl = 1;
+    if ((int)blockIdx.x < g.full_tiles) {
+        const int nwg = g.full_tiles;
         int bid = blockIdx.x;
         const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
         const int per_group = 8 * g.tiles_n;
         const int grp = bid / per_group, first_tm = grp * 8;
-        const int gsz = (g.tiles_m - first_tm) < 8 ? (g.tiles_m - first_tm) : 8;
+        const int gsz = (g.full_tm - first_tm) < 8 ? (g.full_tm - first_tm) : 8;
         const int in_g = bid - grp * per_group;
         tm = first_tm + in_g % gsz; tn = in_g / gsz;
-        tm = __builtin_amdgcn_readfirstlane(tm); tn = __builtin_amdgcn_readfirstlane(tn);
+    } else {
+        const int idx = blockIdx.x - g.full_tiles, rows = g.tiles_m - g.full_tm;
+        ksl = g.tail_s;
+        kz = idx % ksl;
+        const int tile = idx / ksl;
+        tm = g.full_tm + tile % rows; tn = tile / rows;
     }
+    tm = __builtin_amdgcn_readfirstlane(tm); tn = __builtin_amdgcn_readfirstlane(tn);
+    kz = __builtin_amdgcn_readfirstlane(kz); ksl = __builtin_amdgcn_readfirstlane(ksl);
     const int m0 = tm * 256, n0 = tn * 256;
 
     TnSide<TA> sa;
@@ -136,8 +147,19 @@ void gemm_bf16_8phase_t_kernel(TnArgs g) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const int nt = (g.K + TN_BK - 1) / TN_BK, t_last = nt - 1;
-    const int k_tail = g.K - t_last * TN_BK;                                       // valid k-rows of the last K-tile (64 unless ragged)
+    // this block's part of the reduction: everything, or K-slice kz of ksl (whole K-tiles; the ragged end belongs to the last slice)
+    int Kl = g.K;
+    const bf16_t* gA = g.A;
+    const bf16_t* gB = g.B;
+    if (ksl > 1) {
+        const int nt_all = (g.K + TN_BK - 1) / TN_BK, per = (nt_all + ksl - 1) / ksl;
+        const int tb = kz * per, te = tb + per < nt_all ? tb + per : nt_all;
+        gA += (long long)tb * (TA ? (long long)TN_BK * g.lda : TN_BK);
+        gB += (long long)tb * (TB ? (long long)TN_BK * g.ldb : TN_BK);
+        Kl = (te * TN_BK < g.K ? te * TN_BK : g.K) - tb * TN_BK;
+    }
+    const int nt = (Kl + TN_BK - 1) / TN_BK, t_last = nt - 1;
+    const int k_tail = Kl - t_last * TN_BK;                                        // valid k-rows of the last K-tile (64 unless ragged)
     const uint32_t lds0 = (uint32_t)(uintptr_t)((tn_lds_void*)smem);
     const char* sm = reinterpret_cast<const char*>(smem);
 
@@ -181,9 +203,9 @@ void gemm_bf16_8phase_t_kernel(TnArgs g) {
     }
 #define TN_TILE_TAIL(b, tt) { \
         const int t1 = (tt) + 1 < t_last ? (tt) + 1 : t_last, t2 = (tt) + 2 < t_last ? (tt) + 2 : t_last; \
-        const bf16_t* pA1 = g.A + (long long)t1 * strideA; \
-        const bf16_t* pA2 = g.A + (long long)t2 * strideA; \
-        const bf16_t* pB2 = g.B + (long long)t2 * strideB; \
+        const bf16_t* pA1 = gA + (long long)t1 * strideA; \
+        const bf16_t* pA2 = gA + (long long)t2 * strideA; \
+        const bf16_t* pB2 = gB + (long long)t2 * strideB; \
         const bool tl1 = ragged && t1 == t_last, tl2 = ragged && t2 == t_last; \
         TN_TILE_P(b, pA1, pA2, pB2, tl1, tl2) \
     }
@@ -191,10 +213,10 @@ void gemm_bf16_8phase_t_kernel(TnArgs g) {
     // ---- prologue: K-tile 0 complete, three half-tiles of the next one in flight
     {
         const int t1 = 1 < t_last ? 1 : t_last;
-        const bf16_t* pA1 = g.A + (long long)t1 * strideA;
-        const bf16_t* pB1 = g.B + (long long)t1 * strideB;
+        const bf16_t* pA1 = gA + (long long)t1 * strideA;
+        const bf16_t* pB1 = gB + (long long)t1 * strideB;
         const bool tl0 = ragged && t_last == 0, tl1 = ragged && t1 == t_last;
-        TN_PF(0, 2, g.B, sb.voff[0], TB && tl0) TN_PF(0, 0, g.A, sa.voff[0], TA && tl0) TN_PF(0, 3, g.B, sb.voff[1], TB && tl0) TN_PF(0, 1, g.A, sa.voff[1], TA && tl0)
+        TN_PF(0, 2, gB, sb.voff[0], TB && tl0) TN_PF(0, 0, gA, sa.voff[0], TA && tl0) TN_PF(0, 3, gB, sb.voff[1], TB && tl0) TN_PF(0, 1, gA, sa.voff[1], TA && tl0)
         TN_PF(1, 2, pB1, sb.voff[0], TB && tl1) TN_PF(1, 0, pA1, sa.voff[0], TA && tl1) TN_PF(1, 3, pB1, sb.voff[1], TB && tl1)
         asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         TN_BAR
@@ -205,8 +227,8 @@ void gemm_bf16_8phase_t_kernel(TnArgs g) {
     int t = 0;
     const int nt_main = (nt - 3 > 0 ? nt - 3 : 0) & ~1;
     {
-        const bf16_t* pa = g.A;
-        const bf16_t* pb = g.B;
+        const bf16_t* pa = gA;
+        const bf16_t* pb = gB;
         for (; t < nt_main; t += 2) {
             TN_TILE_P(0, pa + strideA, pa + 2 * strideA, pb + 2 * strideB, false, false)
             TN_TILE_P(1, pa + 2 * strideA, pa + 3 * strideA, pb + 3 * strideB, false, false)
@@ -224,6 +246,34 @@ void gemm_bf16_8phase_t_kernel(TnArgs g) {
 
     // ---- epilogue: acc[nh*2+jj][mh*4+ii][r] = C[m][n + r],  m = m0 + 128 mh + 64 wr + 16 ii + (lane & 15),
     //                                                       n = n0 + 128 nh + 32 wc + 16 jj + 4 (lane >> 4)
+    if (ksl > 1) {
+        // K-slice of a tail tile: fp32 partial sums into this slice's slab (rows relative to the first tail row, row stride N)
+        const int row0 = g.full_tm * 256;
+        float* slab = g.ws + (long long)kz * (g.M - row0) * g.N;
+        const bool vec4 = (g.N & 3) == 0;
+#pragma unroll
+        for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+            for (int ii = 0; ii < 4; ++ii) {
+                const int m = m0 + 128 * mh + 64 * wr + 16 * ii + (lane & 15);
+                if (m >= g.M) continue;
+#pragma unroll
+                for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj) {
+                        const int n = n0 + 128 * nh + 32 * wc + 16 * jj + 4 * (lane >> 4);
+                        if (n >= g.N) continue;
+                        const f32x4 v = acc[nh * 2 + jj][mh * 4 + ii];
+                        float* sp = slab + (long long)(m - row0) * g.N + n;
+                        if (vec4) *reinterpret_cast<f32x4*>(sp) = v;
+                        else {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) if (n + r < g.N) sp[r] = v[r];
+                        }
+                    }
+            }
+        return;
+    }
     TC* C = reinterpret_cast<TC*>(g.C);
     const bool vec = (g.ldc & 3) == 0;
 #pragma unroll
@@ -268,6 +318,10 @@ void gemm_bf16_8phase_t_kernel(TnArgs g) {
         }
 }
 
+// gemm_fast.hip
+void egomi_plan_tail_rows(int M, int N, int K, long long ws_bytes, int* rows, int* slices);
+int egomi_splitk_reduce_rows(void* C, int c_dtype, long long ldc, int rows, int N, const float* ws, int slices, int accumulate, hipStream_t s);
+
 // kernel id reported by egomi_gemm_kernel_id for this kernel
 #define TN_KERNEL_ID 3
 
@@ -293,6 +347,35 @@ static bool tn_applicable(const egomi_gemm_desc* d) {
     return tiles >= 64;                                                            // fewer tiles: the generic kernel's smaller tiles fill the chip better
 }
 
+// ragged last round: the last `rows` tile rows as `slices` K-slices (the plan of the K-contiguous kernel, gemm_fast.hip plan_tail; slabs behind
+// the ticket words of the caller's scratch).  rows = 0: every tile whole.
+static void tn_tail(const egomi_gemm_desc* d, int* rows, int* slices, float** slabs) {
+    *rows = 0; *slices = 1; *slabs = nullptr;
+    static int no_tail = -1;
+    if (no_tail < 0) { const char* e = getenv("EGOMI_GEMM_NO_TAIL"); no_tail = e ? atoi(e) : 0; }
+    if (!d->workspace || no_tail) return;
+    char* wsp = (char*)d->workspace;
+    long long wsb = d->workspace_bytes;
+    if (d->ws_tickets_zeroed) { wsp += 4096; wsb -= 4096; }
+    if (wsb <= 0 || (((uintptr_t)wsp) & 15)) return;
+    int r = 0, sl = 1;
+    egomi_plan_tail_rows(d->M, d->N, d->K, wsb, &r, &sl);
+    const int nt = (d->K + TN_BK - 1) / TN_BK;
+    if (r <= 0 || sl < 2 || nt / sl < 8) return;                                   // (every slice keeps whole K-tiles to work on)
+    *rows = r; *slices = sl; *slabs = (float*)wsp;
+}
+
+// 0 and the plan of the launch egomi_gemm would make for this descriptor (*slices = 0: no K-sliced rows), or EGOMI_E_UNSUPPORTED
+extern "C" int egomi_gemm_tn_tail_plan(const egomi_gemm_desc* d, int* row0, int* slices) {
+    if (!d || !row0 || !slices) return EGOMI_E_BADARG;
+    if (!tn_applicable(d)) return EGOMI_E_UNSUPPORTED;
+    int r, sl; float* w;
+    tn_tail(d, &r, &sl, &w);
+    *row0 = r ? ((d->M + 255) / 256 - r) * 256 : d->M;
+    *slices = r ? sl : 0;
+    return EGOMI_OK;
+}
+
 extern "C" int egomi_gemm_tn_kernel_id(const egomi_gemm_desc* d) { return (d && tn_applicable(d)) ? TN_KERNEL_ID : 0; }
 
 // returns 0 on success, < 0 on error, 1 when this kernel does not apply
@@ -302,7 +385,12 @@ int egomi_gemm_tn_try(const egomi_gemm_desc* d, hipStream_t s) {
     g.A = (const bf16_t*)d->A; g.B = (const bf16_t*)d->B; g.C = d->C;
     g.M = d->M; g.N = d->N; g.K = d->K; g.lda = d->lda; g.ldb = d->ldb; g.ldc = d->ldc; g.accumulate = d->accumulate;
     g.tiles_m = (d->M + 255) / 256; g.tiles_n = (d->N + 255) / 256;
-    const dim3 grid(g.tiles_m * g.tiles_n), block(512);
+    g.full_tm = g.tiles_m; g.full_tiles = g.tiles_m * g.tiles_n; g.tail_s = 1; g.ws = nullptr;
+    int rows = 0, slices = 1;
+    float* slabs = nullptr;
+    tn_tail(d, &rows, &slices, &slabs);
+    if (rows > 0) { g.full_tm = g.tiles_m - rows; g.full_tiles = g.full_tm * g.tiles_n; g.tail_s = slices; g.ws = slabs; }
+    const dim3 grid(g.full_tiles + rows * g.tiles_n * slices), block(512);
     const bool f32 = d->c_dtype == EGOMI_F32;
     if (d->a_layout == 1) {
         if (f32) EGOMI_LAUNCH((gemm_bf16_8phase_t_kernel<float, true, true>), grid, block, 0, s, g);
@@ -310,6 +398,11 @@ int egomi_gemm_tn_try(const egomi_gemm_desc* d, hipStream_t s) {
     } else {
         if (f32) EGOMI_LAUNCH((gemm_bf16_8phase_t_kernel<float, false, true>), grid, block, 0, s, g);
         else EGOMI_LAUNCH((gemm_bf16_8phase_t_kernel<bf16_t, false, true>), grid, block, 0, s, g);
+    }
+    if (rows > 0) {
+        const long long row0 = (long long)g.full_tm * 256;
+        const int esz = f32 ? 4 : 2;
+        return egomi_splitk_reduce_rows((char*)d->C + row0 * d->ldc * esz, d->c_dtype, d->ldc, d->M - (int)row0, d->N, g.ws, slices, d->accumulate, s);
     }
     return egomi_launch_status();
 }

@@ -16,6 +16,12 @@ all-gather across all 7 xGMI links rather than a ring"):
   small buckets :  one fp32 all-reduce.
 Every rank ends with bit-identical values (the all-gather distributes one copy of each reduced chunk), so replicas do not
 drift.  Averaging (1/world) is folded into the optimizer's grad_scale.
+
+resident=True (EgoAdamW + bf16 decoder layers, `--unfreeze_language_model`): a decoder layer's bucket IS its bf16 wire buffer, kept
+per layer.  The engine's weight-gradient products write their bf16 result straight into it (the rounding the packing cast would
+apply, applied by the GEMM epilogue), the collectives run in place, and the optimizer reads the rank-summed bf16 gradient from it
+(egomi_adamw_g16): no fp32 -> bf16 packing pass and no bf16 -> fp32 widening pass, 12 of the 24 B per parameter the exchange moved
+through HBM on every rank.  Values are bit-identical to the packed route.
 """
 import torch
 import torch.distributed as dist
@@ -66,7 +72,7 @@ class GradSync:
     reduced on a side stream as soon as they close; `finish()` joins.  wire_dtype=torch.bfloat16: buckets of at least
     `wire_min_bytes` cross the fabric as bf16 with fp32 accumulation (see the module docstring)."""
 
-    def __init__(self, group=None, wire_dtype=None, wire_min_bytes=32 << 20, bucket_bytes=256 << 20, run_single=False):
+    def __init__(self, group=None, wire_dtype=None, wire_min_bytes=32 << 20, bucket_bytes=256 << 20, run_single=False, resident=False):
         """bucket_bytes: loose tensors are packed until the open bucket reaches this size.  256 MB: in frozen-LLM mode the lm_head
         gradient (0.53 GB, final at the very START of backward) closes its own bucket at once and crosses the fabric under the 32
         layers' backward; with 1 GB it sat in the open bucket until the embedding gradient arrived at the end of backward and
@@ -90,6 +96,8 @@ class GradSync:
         # has all-to-all, and so has gloo for host tensors; gloo with DEVICE tensors (two ranks rehearsing on one card) has not and
         # gathers everything instead.  On RCCL every error of a collective propagates.
         self.backend = dist.get_backend(group) if dist.is_initialized() else None
+        self.resident = bool(resident) and wire_dtype is not None   # decoder-layer buckets stay in their wire buffers (module docstring)
+        self._resident = {}                        # tag -> persistent wire buffer [W * c]
         self.time_exposed = False                  # bench.py: event pair around finish()'s join = what the exchange costs the step
         self._exposed = []
 
@@ -111,6 +119,40 @@ class GradSync:
             return
         self.flush()
         self._reduce(flat.view(-1), None)
+
+    def resident_wire(self, tag, n, device):
+        """The persistent wire buffer [W * c] of bucket `tag` holding n elements (pad zero), or None when the bucket would not travel
+        in wire_dtype (too small / resident mode off / nothing to exchange)."""
+        if self.skip or not self.resident or n * 4 < self.wire_min_bytes:
+            return None
+        W = self.world
+        c = -(-n // (W * 8)) * 8
+        t = self._resident.get(tag)
+        if t is None or t.numel() != W * c or t.device != device:
+            t = self._resident[tag] = torch.zeros(W * c, dtype=self.wire_dtype, device=device)
+        return t
+
+    def ready_resident(self, tag, wire):
+        """`wire` (resident_wire(tag, ...)) holds this rank's gradients in wire precision: exchanged in place; afterwards it holds the sum
+        over ranks, for the optimizer to read."""
+        self.flush()
+        self._bucket_id += 1
+        W, cuda = self.world, wire.is_cuda
+        c = wire.numel() // W
+        if cuda:
+            if self.stream is None:
+                self.stream = torch.cuda.Stream()
+            self.stream.wait_stream(torch.cuda.current_stream())
+        with (torch.cuda.stream(self.stream) if cuda else _Null()):
+            recv = self._buf("recv", W * c, self.wire_dtype, wire.device)
+            red = self._buf("red", c, self.wire_dtype, wire.device)
+            self._all_to_all(recv, wire, W, c)
+            _rank_sum(recv.view(W, c), red)
+            dist.all_gather_into_tensor(wire, red, group=self.group)
+        self.stats["collective_calls"] += 2
+        self.stats["wire_bytes"] += 2 * (W - 1) * c * wire.element_size()
+        self.stats["buckets"] += 1
+        self.stats["resident_buckets"] = self.stats.get("resident_buckets", 0) + 1
 
     def flush(self):
         if self.skip or not self.open:

@@ -221,7 +221,7 @@ def train(args, model, train_data, val_data=None, device="cuda", log=print, step
     accum = max(1, int(getattr(args, "grad_accum_steps", 1) or 1))
     micro = micro_batch_per_rank(args.bs, accum, world)
     opt = EgoAdamW(model, lr=float(args.lr_llm))
-    sync = GradSync(wire_dtype=torch.bfloat16 if model.engine.dtype == torch.bfloat16 else None) if world > 1 else None
+    sync = GradSync(wire_dtype=torch.bfloat16 if model.engine.dtype == torch.bfloat16 else None, resident=True) if world > 1 else None     # EgoAdamW reads the wire
     start_epoch, global_step, best_ade = 0, 0, float("inf")
     os.makedirs(args.out_dir, exist_ok=True)
     latest = os.path.join(args.out_dir, "latest_model.pt")

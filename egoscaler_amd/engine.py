@@ -57,6 +57,9 @@ class Engine:
         self.trainable: Dict[str, bool] = {}
         self.ctx = None
         self.grad_sync = None          # optional dp.GradSync: notified when a gradient buffer is final
+        self.reduced_grad = {}         # resident exchange (dp.GradSync(resident=True)): name -> bf16 view of the rank-summed gradient in the
+        self.layer_offs = {}           # layer's wire buffer, read by EgoAdamW; layer_offs[l][name] = element offset inside the layer's flat block
+        self._direct, self._direct_done = None, set()
         self.use_fused_attention = True
         self.use_fused_swiglu = os.environ.get("EGOMI_NO_FUSED_SWIGLU", "0") != "1"   # SwiGLU in the gate|up GEMM epilogue where the 256x256
                                                                                       # kernel runs (tests and A/B runs switch it off)
@@ -78,8 +81,41 @@ class Engine:
     def _notify_layer(self, l):
         """A decoder layer's gradients are final: its flat block goes out as one bucket (bucketed per layer,
         reverse layer order, overlapped with the rest of backward)."""
-        if self.grad_sync is not None and l in self.layer_flat:
-            self.grad_sync.ready_flat(f"layer{l}", self.layer_flat[l])
+        if self.grad_sync is None or l not in self.layer_flat:
+            return
+        if self._direct is not None:
+            wire, views = self._direct
+            for n, v in views.items():                                   # what no product wrote in wire precision (the two norm weights; a
+                if n not in self._direct_done:                           # product the k-major kernel refused): cast from the fp32 block
+                    if n in self.grad_fresh:
+                        self.main_grad[n].zero_()
+                        self.grad_fresh.discard(n)
+                    ops.cast(self.main_grad[n].view(-1), wire.dtype, out=v.view(-1))
+                self.reduced_grad[n] = v
+            self._direct, self._direct_done = None, set()
+            self.grad_sync.ready_resident(f"layer{l}", wire)
+            return
+        self.grad_sync.ready_flat(f"layer{l}", self.layer_flat[l])
+
+    def _begin_direct(self, l):
+        """Resident exchange: this layer's weight gradients are produced in wire precision inside the layer's wire buffer (dp.py).  Only
+        where every gradient of the layer is overwritten by this backward (no accumulation over micro-batches) on the bf16 k-major route."""
+        self._direct, self._direct_done = None, set()
+        gs = self.grad_sync
+        if gs is None or not getattr(gs, "resident", False) or not self.use_tn or self.dtype != torch.bfloat16:
+            return
+        names = [n for n in self.layer_param_names(l) if n in self.trainable]
+        if not names:
+            return
+        if l not in self.layer_flat:
+            self._alloc_layer_grads(l)
+        if any(self.w[n].dim() == 2 and n not in self.grad_fresh for n in names):
+            return                                                       # accumulating: fp32 block + packing cast, as without resident mode
+        wire = gs.resident_wire(f"layer{l}", self.layer_flat[l].numel(), self.device)
+        if wire is None:
+            return
+        offs = self.layer_offs[l]
+        self._direct = (wire, {n: wire[offs[n]:offs[n] + self.w[n].numel()].view(self.w[n].shape) for n in names})
 
     # ------------------------------------------------------------------------------------ setup
     def fold_batchnorm(self):
@@ -207,6 +243,7 @@ class Engine:
             total += (self.w[n].numel() + 63) // 64 * 64
         flat = torch.zeros(total, dtype=torch.float32, device=self.device)
         self.layer_flat[l] = flat
+        self.layer_offs[l] = dict(zip(names, offs))
         for n, o in zip(names, offs):
             self.main_grad[n] = flat[o:o + self.w[n].numel()].view(self.w[n].shape)
 
@@ -555,6 +592,13 @@ class Engine:
         into zero-padded [*, M64] buffers so the product runs K-contiguous on the tuned kernel."""
         if name not in self.trainable:
             return
+        if self._direct is not None and name in self._direct[1] and name in self.grad_fresh:
+            v = self._direct[1][name]
+            if ops.mm_kernel_id(dY, X, v, a_layout=1, b_layout=1) == 3:
+                ops.mm(dY, X, out=v, a_layout=1, b_layout=1)             # bf16 result straight into the layer's wire buffer
+                self.grad_fresh.discard(name)
+                self._direct_done.add(name)
+                return
         g = self.grad_buffer(name)
         # a buffer still marked fresh has not been zeroed this step (lazy_zero_names): the first product overwrites it,
         # which saves the zero pass and the read of C (26 GB each per step when every layer is trained)
@@ -566,6 +610,14 @@ class Engine:
         """The gradients of weights that share their input X (q|k|v, gate|up), dY [M, sum N_i] holding their output gradients side
         by side: ONE product into the stacked view of their gradient buffers when those lie back to back in the layer's flat block
         and agree on overwrite-vs-accumulate; the separate products otherwise."""
+        if self._direct is not None and all(n in self._direct[1] and n in self.grad_fresh for n in names):
+            g = self._side_by_side([self._direct[1][n] for n in names])
+            if g is not None and ops.mm_kernel_id(dY, X, g, a_layout=1, b_layout=1) == 3:
+                ops.mm(dY, X, out=g, a_layout=1, b_layout=1)
+                for n in names:
+                    self.grad_fresh.discard(n)
+                    self._direct_done.add(n)
+                return
         if self.use_tn and self.dtype == torch.bfloat16 and all(n in self.trainable for n in names):
             gs = [self.grad_buffer(n) for n in names]
             fresh = [n in self.grad_fresh for n in names]
@@ -621,6 +673,7 @@ class Engine:
             p = f"model.layers.{l}."
             lc = ctx["layers"][l]
             gu, qkv = lc["gu"], lc["qkv"]
+            self._begin_direct(l)
             # ---- MLP
             d_act = self._dgrad(dx, p + "mlp.down_proj.weight", ws.get("d_act", (M, Fd), T))
             self._wgrad(p + "mlp.down_proj.weight", dx, lc["act"])
@@ -736,6 +789,7 @@ class Engine:
                           out=self.ws.get("d_hn", hn.shape, self.dtype))
         else:
             d_hn = ops.mm(d_logits, W, out=self.ws.get("d_hn", hn.shape, self.dtype), b_layout=1)
+        self.reduced_grad.clear()                                # views of the previous step's exchange: consumed by the optimizer since
         self._wgrad("lm_head.weight", d_logits, hn)
         if self.grad_sync is not None:
             self.grad_sync.begin_step()

@@ -465,7 +465,9 @@ def cross_entropy(logits, targets, ignore_index, dlogits=None, grad_scale=1.0):
 
 
 def adamw(master, model_copy, grad, m, v, lr, beta1, beta2, eps, wd, step, grad_scale=1.0):
-    call("egomi_adamw", P(master), P(model_copy), P(grad), P(m), P(v), c_i64(master.numel()), c_f(lr), c_f(beta1), c_f(beta2), c_f(eps),
+    if grad.dtype not in (torch.float32, torch.bfloat16) or not grad.is_contiguous() or grad.numel() != master.numel():
+        raise _lib.EgomiError("adamw: the gradient must be a contiguous fp32 or bf16 tensor of the parameter's size")
+    call("egomi_adamw" if grad.dtype == torch.float32 else "egomi_adamw_g16", P(master), P(model_copy), P(grad), P(m), P(v), c_i64(master.numel()), c_f(lr), c_f(beta1), c_f(beta2), c_f(eps),
          c_f(wd), c_i(step), c_f(grad_scale), c_i(dt(model_copy.dtype) if model_copy is not None else F32), S())
 
 

@@ -21,7 +21,9 @@ class EgoAdamW:
         lr = self.lr if lr is None else lr
         eng = self.model.engine
         for n, st in self.state.items():
-            g = eng.main_grad.get(n)
+            g = eng.reduced_grad.get(n)                    # resident exchange (dp.GradSync(resident=True)): the rank-summed bf16 gradient, read
+            if g is None:                                  # in place from the layer's wire buffer
+                g = eng.main_grad.get(n)
             if g is None:
                 continue
             p = st["p"]

@@ -369,7 +369,7 @@ class TrajPointLLMForCausalLM(nn.Module):
         eng.flush_fresh()
         for n, p in self.named_parameters():
             if n in eng.trainable:
-                g = eng.main_grad[n]
+                g = eng.reduced_grad.get(n, eng.main_grad[n])     # (resident exchange: the bf16 view the optimizer will read)
                 p.main_grad = g
                 if p.dtype == torch.float32:
                     p.grad = g

@@ -165,6 +165,10 @@ int egomi_gemm_slab_count(const egomi_gemm_desc* desc);   /* EGOMI_EPI_SLABS: sl
  * area (workspace + 4096 when ws_tickets_zeroed) for egomi_rmsnorm_fwd_tail / egomi_rmsnorm_bwd_tail to sum.  bf16 output, no
  * bias / activation / alpha / accumulate.  slices = 0: the plan has no tail rows, nothing is pending. */
 int egomi_gemm_tail_plan(const egomi_gemm_desc* desc, int* row0, int* slices);
+/* Query only, for k-major products (egomi_gemm_kernel_id == 3: the weight / data gradients of nn.Linear's backward, train.py:183): the
+ * rows [row0, M) egomi_gemm will compute as `slices` K-slices and sum in its own combine pass (ragged last round of 256x256 tiles);
+ * slices = 0: none.  EGOMI_E_UNSUPPORTED when the descriptor does not take that kernel. */
+int egomi_gemm_tn_tail_plan(const egomi_gemm_desc* desc, int* row0, int* slices);
 /* Measurement hooks (bench.py `roofline`; no reference counterpart).  egomi_gemm_time_next(start, stop): the NEXT egomi_gemm call
  * of this thread, if it takes the 256x256 kernel (egomi_gemm_kernel_id == 2), records `start` right before and `stop` right after
  * THAT kernel on the launch stream — the slab-combine pass of K-sliced tail rows is a separate kernel and lies outside the
@@ -391,6 +395,10 @@ int egomi_ce_fwd_bwd(const void* logits, int64_t ld, const int64_t* targets, int
  * fp32 master/moments/grad; model_copy (copy_dtype, may be NULL) receives the updated value. */
 int egomi_adamw(float* master, void* model_copy, const float* grad, float* m, float* v, int64_t n, float lr, float beta1,
                 float beta2, float eps, float weight_decay, int step, float grad_scale, int copy_dtype, egomi_stream_t stream);
+/* The same step with the gradient given in bf16: the rank-summed wire buffer of the data-parallel exchange read in place (what DeepSpeed's
+ * bf16 engine does after its reduce: fp32 master / moments updated from the reduced low-precision gradient, train.py:92-104,184). */
+int egomi_adamw_g16(float* master, void* model_copy, const void* grad_bf16, float* m, float* v, int64_t n, float lr, float beta1,
+                    float beta2, float eps, float weight_decay, int step, float grad_scale, int copy_dtype, egomi_stream_t stream);
 
 /* layout helpers: out[c, r] = in[r, c] for r < R, zero for R <= r < ldo; cast; add */
 int egomi_transpose(const void* in, int R, int C, int64_t ldi, void* out, int64_t ldo, int dtype, egomi_stream_t stream);

@@ -49,3 +49,35 @@ def test_advice_r2_reproducer_shape():
     assert rc != 0 or sl.value < 2 or (setattr(d, "epilogue", 2) or L.egomi_gemm_kernel_id(ctypes.byref(d)) == 2)
     d.epilogue = 0
     assert L.egomi_gemm_kernel_id(ctypes.byref(d)) == 2       # the undeferred call still takes the every-row-sliced 256x256 form
+
+
+def tn_desc(M, N, K, a_layout, c_dtype=BF16, ws=True):
+    d = desc(M, N, K)
+    d.a_layout, d.b_layout = a_layout, 1
+    d.lda = M if a_layout == 1 else K
+    d.ldb, d.ldc, d.c_dtype = N, N, c_dtype
+    if not ws:
+        d.workspace, d.workspace_bytes, d.ws_tickets_zeroed = None, 0, 0
+    return d
+
+
+def test_k_major_products_slice_the_ragged_last_round():
+    """The unfrozen step's data gradients at M = 5536, N = 4096 are 352 tiles of 256x256 on 256 CUs (2 rounds for 1.375 rounds of work):
+    the k-major kernel K-slices its last tile rows like the K-contiguous one.  Exact multiples of a round and products without scratch
+    stay whole; every slice keeps >= 8 K-tiles; the slabs fit the scratch."""
+    from egoscaler_amd.ops import F32
+    L = _lib.lib()
+    row0, sl = ctypes.c_int(0), ctypes.c_int(0)
+    for K in (4096, 12288, 22016):                                         # o_proj, [Wq;Wk;Wv], [Wgate;Wup] data gradients
+        d = tn_desc(5536, 4096, K, 0)
+        assert L.egomi_gemm_kernel_id(ctypes.byref(d)) == 3
+        assert L.egomi_gemm_tn_tail_plan(ctypes.byref(d), ctypes.byref(row0), ctypes.byref(sl)) == 0
+        assert sl.value >= 2 and row0.value % 256 == 0 and 0 <= row0.value < 5536, (K, row0.value, sl.value)
+        assert (K // 64) // sl.value >= 8
+        assert (5536 - row0.value) * 4096 * 4 * sl.value <= d.workspace_bytes - 4096
+        dn = tn_desc(5536, 4096, K, 0, ws=False)
+        assert L.egomi_gemm_tn_tail_plan(ctypes.byref(dn), ctypes.byref(row0), ctypes.byref(sl)) == 0 and sl.value == 0 and row0.value == 5536
+    d = tn_desc(12288, 4096, 5536, 1, c_dtype=F32)                         # stacked q|k|v weight gradient: 768 tiles = 3 rounds exactly
+    assert L.egomi_gemm_tn_tail_plan(ctypes.byref(d), ctypes.byref(row0), ctypes.byref(sl)) == 0 and sl.value == 0
+    d = tn_desc(300, 200, 512, 1)                                          # not a product of that kernel
+    assert L.egomi_gemm_tn_tail_plan(ctypes.byref(d), ctypes.byref(row0), ctypes.byref(sl)) != 0

@@ -56,7 +56,7 @@ def _worker(rank, world, port, wire, q):
         dims = _dims()
         m = _build(dims, True)
         opt = EgoAdamW(m, lr=1e-3)
-        sync = GradSync(wire_dtype=torch.bfloat16 if wire else None, wire_min_bytes=1 << 16)
+        sync = GradSync(wire_dtype=torch.bfloat16 if wire else None, wire_min_bytes=1 << 16, resident=(wire == "resident"))
         m.engine.grad_sync = sync
         toks, masks, Lp, pts, start = _batch(dims, 4)
         lo, hi = shard_range(4, rank, world)
@@ -64,7 +64,8 @@ def _worker(rank, world, port, wire, q):
         sync.finish()
         names = ["lm_head.weight", "model.embed_tokens.weight", "model.layers.0.self_attn.q_proj.weight", "model.layers.1.mlp.down_proj.weight",
                  "model.point_proj.0.weight", "model.norm.weight"]
-        grads = {n: (m.engine.main_grad[n] * sync.grad_scale).float().cpu().numpy() for n in names}      # numpy: pickled by value
+        # (resident exchange: the decoder layers' reduced gradients live in their bf16 wire buffers, engine.reduced_grad)
+        grads = {n: (m.engine.reduced_grad.get(n, m.engine.main_grad[n]).float() * sync.grad_scale).cpu().numpy() for n in names}      # numpy: pickled by value
         opt.step(grad_scale=sync.grad_scale)
         w = {n: dict(m.named_parameters())[n].detach().float().cpu().numpy() for n in names}
         q.put((rank, float(loss), grads, w, dict(sync.stats)))
@@ -73,8 +74,7 @@ def _worker(rank, world, port, wire, q):
 
 
 @pytest.mark.timeout(300)
-@pytest.mark.parametrize("wire", [False, True])
-def test_two_ranks_match_single_process_full_batch(wire):
+def _two_ranks(wire):
     import torch.multiprocessing as mp
     world, port = 2, _free_port()
     ctx = mp.get_context("spawn")
@@ -86,6 +86,25 @@ def test_two_ranks_match_single_process_full_batch(wire):
     for p in ps:
         p.join(60)
         assert p.exitcode == 0
+    return res
+
+
+@pytest.mark.timeout(300)
+def test_resident_exchange_equals_packed_exchange_bitwise():
+    """dp.GradSync(resident=True): the decoder layers' buckets are exchanged inside their bf16 wire buffers and read there by the optimizer
+    (egomi_adamw_g16) — the same reduced gradients and the same weights after the step as the packed route, bit for bit, on both ranks."""
+    a, b = _two_ranks(True), _two_ranks("resident")
+    for r in range(2):
+        for n in a[r][2]:
+            assert np.array_equal(a[r][2][n], b[r][2][n]), n
+            assert np.array_equal(a[r][3][n], b[r][3][n]), n
+    assert b[0][4].get("resident_buckets") == _dims().lm.num_hidden_layers and a[0][4]["wire_bytes"] == b[0][4]["wire_bytes"]
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("wire", [False, True])
+def test_two_ranks_match_single_process_full_batch(wire):
+    res = _two_ranks(wire)
     # single process, whole batch
     dims = _dims()
     m = _build(dims, True)

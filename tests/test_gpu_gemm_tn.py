@@ -73,6 +73,40 @@ def test_dgrad_form_bf16_out(ops, M, N, K, acc):
     assert rel(C, ref) < 2e-2, rel(C, ref)
 
 
+@pytest.mark.parametrize("form,M,N,K,acc", [("dgrad", 5536, 4096, 12288, False), ("dgrad", 5536, 4096, 22016, False), ("dgrad", 5536, 4096, 4096, True),
+                                            ("wgrad", 22016, 4096, 5536, True), ("wgrad", 4608, 4096, 5532, False), ("wgrad", 2048, 11008, 5532, True)])
+def test_k_sliced_tail_rows(ops, form, M, N, K, acc):
+    """Ragged last round: the last tile rows are computed as K-slices (fp32 slabs in the scratch) and summed by the combine pass
+    (egomi_gemm_tn_tail_plan says which rows).  The sliced rows must be as good as the whole ones: compared separately, with the ragged
+    reduction tail (K % 64 != 0) inside the last slice, accumulation into C on both kinds of rows, bf16 and fp32 outputs."""
+    import ctypes
+    from egoscaler_amd import _lib
+    wg = form == "wgrad"
+    a = rnd(K, M, seed=31) if wg else rnd(M, K, seed=31)
+    b = rnd(K, N, seed=32, scale=0.05)
+    A, B = a.cuda(), b.cuda()
+    odt = torch.float32 if wg else torch.bfloat16
+    C0 = torch.randn(M, N, generator=torch.Generator().manual_seed(33)).to(odt)
+    C = C0.clone().cuda() if acc else torch.full((M, N), float("nan"), dtype=odt, device="cuda")
+    al = 1 if wg else 0
+    assert ops.mm_kernel_id(A, B, C, a_layout=al, b_layout=1, accumulate=acc) == 3
+    d = ops.GemmDesc()
+    d.A, d.B, d.C, d.M, d.N, d.K = A.data_ptr(), B.data_ptr(), C.data_ptr(), M, N, K
+    d.lda, d.ldb, d.ldc, d.a_layout, d.b_layout = A.stride(0), N, N, al, 1
+    d.ab_dtype, d.c_dtype, d.batch, d.alpha, d.accumulate = ops.BF16, ops.dt(odt), 1, 1.0, int(acc)
+    ws = ops._tail_workspace(A.device)
+    d.workspace, d.workspace_bytes, d.ws_tickets_zeroed = ws.data_ptr(), ws.numel() * 4, 1
+    row0, sl = ctypes.c_int(0), ctypes.c_int(0)
+    assert _lib.lib().egomi_gemm_tn_tail_plan(ctypes.byref(d), ctypes.byref(row0), ctypes.byref(sl)) == 0
+    assert sl.value >= 2 and 0 <= row0.value < M, (row0.value, sl.value)          # these shapes were chosen because the plan slices them
+    ops.mm(A, B, out=C, a_layout=al, b_layout=1, accumulate=acc)
+    ref = (a.float().t() if wg else a.float()) @ b.float() + (C0.float() if acc else 0)
+    tol = 2e-3 if wg else 2e-2
+    r0 = row0.value
+    assert rel(C[:r0], ref[:r0]) < tol and rel(C[r0:], ref[r0:]) < tol, (rel(C[:r0], ref[:r0]), rel(C[r0:], ref[r0:]))
+    assert float(ws[:1024].abs().max()) == 0                                       # the ticket words ahead of the slabs stay zero
+
+
 def test_products_the_kernel_refuses_still_run(ops):
     a, b = rnd(300, 200, seed=21).cuda(), rnd(300, 136, seed=22).cuda()          # few tiles
     C = torch.zeros(200, 136, device="cuda")

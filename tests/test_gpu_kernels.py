@@ -248,6 +248,28 @@ def test_adamw_matches_torch(ops):
     assert torch.equal(copy.cpu(), master.cpu().bfloat16())
 
 
+@pytest.mark.parametrize("n,off,with_copy", [(5003, 0, True), (4096, 0, False), (1001, 1, True), (3, 0, True), (70000, 4, True)])
+def test_adamw_vector_form_equals_scalar_form(ops, n, off, with_copy):
+    """The 16-B form (aligned buffers, n >= 4; a scalar launch finishes n % 4) against the 4-B form, which the same call takes when a
+    buffer is not 16-B aligned (views at an odd element offset): identical bits in master, m, v and the bf16 model copy."""
+    def at(vals, o, dtype=torch.float32):                  # the same values, placed o elements into a fresh buffer
+        buf = torch.zeros(n + 8, dtype=dtype, device="cuda")
+        buf[o:o + n] = vals.cuda().to(dtype)
+        return buf[o:o + n]
+    vals = [rnd(n, seed=s) for s in (0, 1, 2, 3)]
+    outs = []
+    for o in (off, 1 if off != 1 else 3):                  # second run: forced onto the scalar form by an odd offset
+        master, m, v, g = at(vals[0], o), at(vals[1], o), at(vals[2].abs(), o), at(vals[3], o)
+        cp = at(torch.zeros(n), o, torch.bfloat16)
+        for step in (1, 2):
+            ops.adamw(master, cp if with_copy else None, g, m, v, 1e-3, 0.9, 0.999, 1e-8, 0.01, step, 0.5)
+        outs.append([t.clone() for t in (master, m, v, cp)])
+    if off == 1:
+        return                                              # both runs scalar: nothing to compare beyond not faulting
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_transpose_cast_add_groupmax_smallk(ops, dtype):
     x = rnd(70, 45, dtype=dtype)

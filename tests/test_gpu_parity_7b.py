@@ -108,7 +108,7 @@ def _check_step(wide, unfreeze):
     dims, toks, masks, Lp, pts, start, sd, ref = wide
     m = _model(dims, sd, unfreeze)
     eng = m.engine
-    prof = ops.GemmProfiler(min_flops=0, kernel_ids=(2,))
+    prof = ops.GemmProfiler(min_flops=0, kernel_ids=(2, 3))
     ops.PROFILER = prof
     try:
         loss = m.loss_and_backward(toks.cuda(), masks.cuda(), pts.cuda(), Lp, dims.tok.pad, fps_start=start)
@@ -117,8 +117,13 @@ def _check_step(wide, unfreeze):
     torch.cuda.synchronize()
 
     # ---- the kernels the bench measures were the ones that ran
-    n8 = len(prof.recs)
-    if toks.shape[0] >= 8:
+    n8 = sum(1 for r in prof.recs if r[3] is not None)              # kernel id 2 (the library brackets that kernel itself), K-contiguous operands
+    n3 = len(prof.recs) - n8                                        # kernel id 3: the k-major 8-phase kernel (gemm_tn.hip)
+    if toks.shape[0] >= 8 and unfreeze:
+        # forward qkv, o, gate|up, down on the K-contiguous kernel; their data gradients (4) and weight gradients (4: [q;k;v] and [gate;up]
+        # stacked) on the k-major one
+        assert n8 >= 4 * LAYERS and n3 >= 8 * LAYERS, f"8-phase GEMM launches: {n8} K-contiguous, {n3} k-major"
+    elif toks.shape[0] >= 8:
         assert n8 >= 8 * LAYERS, f"8-phase GEMM launches: {n8}"      # fwd qkv,o,gate|up,down + their dgrads per layer
     else:
         assert n8 >= 2 * LAYERS, f"8-phase GEMM launches: {n8}"      # M = 1384: the long-K products (down_proj, the K-concatenated dgrads)
@@ -128,7 +133,10 @@ def _check_step(wide, unfreeze):
         d, f = dims.lm.hidden_size, dims.lm.intermediate_size
         assert eng.wqkv[0].shape == (3 * d, d) and eng.wqkvT[0].shape == (d, 3 * d) and eng.wgu[0].shape == (2 * f, d) and eng.wguT[0].shape == (d, 2 * f)
     else:
-        assert not eng.wqkv and not eng.wgu                 # trainable weights are not stacked (their copies would go stale)
+        # trainable weights are stacked as VIEWS of the side-by-side parameters (a copy would go stale with every optimizer step)
+        assert not eng.wgu and not eng.wqkvT and sorted(eng.wqkv) == sorted(eng.wgu_cat) == list(range(LAYERS))
+        assert eng.wqkv[0].data_ptr() == eng.w["model.layers.0.self_attn.q_proj.weight"].data_ptr()
+        assert eng.wgu_cat[1].data_ptr() == eng.w["model.layers.1.mlp.gate_proj.weight"].data_ptr()
 
     # ---- loss
     assert abs(float(loss) - ref["loss"]) < LOSS_TOL * abs(ref["loss"]), (float(loss), ref["loss"])

@@ -42,7 +42,7 @@ for N, K in ((4096, 4096), (11008, 4096), (4096, 11008)):
                 "nt_us": round(t_nt * 1e6, 1), "nt_TFLOPs": round(fl / t_nt / 1e12, 1), "transposes_us": round(t_tr * 1e6, 1)})
     del dY, X, dYt, Xt, G
     torch.cuda.empty_cache()
-for N, K in ((4096, 4096), (11008, 4096), (4096, 11008)):          # dX[R, K] = dY[R, N] . W[N, K]
+for N, K in ((4096, 4096), (11008, 4096), (4096, 11008), (12288, 4096), (22016, 4096)):          # dX[R, K] = dY[R, N] . W[N, K]; the last two: [Wq;Wk;Wv], [Wgate;Wup]
     nb = 6
     dY = [torch.randn(R, N, device=dev, generator=g).bfloat16() for _ in range(nb)]
     W = [(torch.randn(N, K, device=dev, generator=g) * 0.02).bfloat16() for _ in range(nb)]
