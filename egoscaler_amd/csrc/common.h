@@ -22,6 +22,16 @@ __device__ __forceinline__ bf16_t f2bf(float f) {
     return *reinterpret_cast<bf16_t*>(&h);
 }
 
+// SwiGLU backward of one element (HF LlamaMLP, modeling_llama.py:174-176: act = silu(gate) * up): d = d(act) -> og = d(gate), ou = d(up).
+// One non-contracted function shared by swiglu_bwd_kernel, the GEMM epilogue EGOMI_EPI_SWIGLU_BWD and its tail-row combine pass, so that the
+// three round identically whatever the surrounding loop shape lets -ffp-contract=fast fuse.
+__device__ __forceinline__ void swiglu_bwd_elem(float d, float g, float u, float& og, float& ou) {
+#pragma clang fp contract(off)
+    const float sg = 1.0f / (1.0f + __expf(-g));
+    ou = d * g * sg;
+    og = d * u * sg * (1.0f + g * (1.0f - sg));
+}
+
 template <typename T> struct Cvt;
 template <> struct Cvt<float> {
     static __device__ __forceinline__ float ld(const float* p) { return *p; }

@@ -499,11 +499,7 @@ __global__ __launch_bounds__(256) void swiglu_bwd_kernel(const T* dact, const T*
         load8<T>(gate + r * ld_in + ci, g);
         load8<T>(up + r * ld_in + ci, u);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float sg = sigmoidf_(g[j]);
-            ou[j] = d[j] * g[j] * sg;
-            og[j] = d[j] * u[j] * sg * (1.0f + g[j] * (1.0f - sg));
-        }
+        for (int j = 0; j < 8; ++j) swiglu_bwd_elem(d[j], g[j], u[j], og[j], ou[j]);
         store8<T>(dgate + r * ld_out + ci, og);
         store8<T>(dup + r * ld_out + ci, ou);
     }

@@ -34,6 +34,7 @@ struct FastArgs {
     int splitk; float* ws;           // splitk > 1: block (tile, blockIdx.y) multiplies its K slice and stores a raw fp32 slab
     int full_tm, full_tiles, tail_s; // 8-phase kernel: M-tile rows >= full_tm are cut into tail_s K-slices (fp32 slabs of those rows only)
     int epi; void* C2; long long ldc2;   // epi 1 (EGOMI_EPI_SWIGLU): C is interleaved-32 gate|up, C2 [M, N/2] receives silu(gate)*up (bf16 only)
+                                         // epi 3 (EGOMI_EPI_SWIGLU_BWD): the product is d(act) [M, N]; C2 = gate|up [M, 2N] (read), C = d(gate|up) [M, 2N]
     int* tickets;                    // non-null: the K-slices of a tail tile are summed INSIDE the launch by the slice block that arrives last
                                      // (one ticket word per tail tile, zero on entry, returned to zero); ws then holds register-major slabs
 };
@@ -601,6 +602,61 @@ void gemm_nt_bf16_8phase_kernel(FastArgs g) {
         // into a private LDS region (144-B pitch) and stores them back as 128-B row segments, 16 B per lane.
         char* wb = reinterpret_cast<char*>(smem) + wave * (64 * 144);
         bf16_t* C = reinterpret_cast<bf16_t*>(g.C);
+        if (g.epi == 3) {
+            // SwiGLU backward in the epilogue of the down_proj data gradient: the wave's 64 columns of d(act) are two interleaved-32 groups,
+            // i.e. 128 consecutive columns of gate|up and of d(gate|up).  d(act) itself never reaches memory.  Four sub-passes of 32 rows:
+            // the gate|up rows come in as 256-B row segments (16 B per lane) into a wave-private LDS strip (272-B pitch), every lane combines
+            // its 4 units x 2 row blocks in place (rounding sequence of swiglu_bwd_kernel on stored bf16 values: d(act) rounded to bf16
+            // first), and the strip leaves as 256-B row segments.  The next sub-pass's rows are in flight meanwhile.
+            char* ws3 = reinterpret_cast<char*>(smem) + wave * (32 * 272);
+            const bf16_t* GU = reinterpret_cast<const bf16_t*>(g.C2);
+            const int lr = lane >> 4, ch = lane & 15;
+            u32x4 in[8];
+#define P8_GU_FETCH(sp_) _Pragma("unroll") for (int it = 0; it < 8; ++it) { \
+                    int m_ = mb + (sp_) * 32 + it * 4 + lr; \
+                    m_ = m_ < g.M ? m_ : g.M - 1; \
+                    in[it] = *reinterpret_cast<const u32x4*>(GU + (long long)m_ * g.ldc2 + 2 * nb + ch * 8); }
+            P8_GU_FETCH(0)
+#pragma unroll
+            for (int sp = 0; sp < 4; ++sp) {
+#pragma unroll
+                for (int it = 0; it < 8; ++it) *reinterpret_cast<u32x4*>(ws3 + (it * 4 + lr) * 272 + ch * 16) = in[it];
+                if (sp < 3) { P8_GU_FETCH(sp + 1) }
+#pragma unroll
+                for (int i2 = 0; i2 < 2; ++i2)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const f32x4 v = acc[j][2 * sp + i2];
+                        char* pg = ws3 + (i2 * 16 + (lane & 15)) * 272 + ((j >> 1) * 64 + (j & 1) * 16 + lr * 4) * 2;
+                        const u32x2 gg = *reinterpret_cast<const u32x2*>(pg), uu = *reinterpret_cast<const u32x2*>(pg + 64);
+                        float og[4], ou[4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float gv = __uint_as_float((r & 1) ? (gg[r >> 1] & 0xFFFF0000u) : (gg[r >> 1] << 16));
+                            const float uv = __uint_as_float((r & 1) ? (uu[r >> 1] & 0xFFFF0000u) : (uu[r >> 1] << 16));
+                            swiglu_bwd_elem(bf2f(f2bf(v[r])), gv, uv, og[r], ou[r]);
+                        }
+                        u32x2 o;
+                        o[0] = (uint32_t)f2bf(og[0]) | ((uint32_t)f2bf(og[1]) << 16);
+                        o[1] = (uint32_t)f2bf(og[2]) | ((uint32_t)f2bf(og[3]) << 16);
+                        *reinterpret_cast<u32x2*>(pg) = o;
+                        o[0] = (uint32_t)f2bf(ou[0]) | ((uint32_t)f2bf(ou[1]) << 16);
+                        o[1] = (uint32_t)f2bf(ou[2]) | ((uint32_t)f2bf(ou[3]) << 16);
+                        *reinterpret_cast<u32x2*>(pg + 64) = o;
+                    }
+#pragma unroll
+                for (int it = 0; it < 8; ++it) {
+                    const int m = mb + sp * 32 + it * 4 + lr;
+                    const u32x4 v = *reinterpret_cast<const u32x4*>(ws3 + (it * 4 + lr) * 272 + ch * 16);
+                    if (m < g.M) *reinterpret_cast<u32x4*>(C + (long long)m * g.ldc + 2 * nb + ch * 8) = v;
+                }
+            }
+#undef P8_GU_FETCH
+            GSTAMP(4)
+            GSTAMP(5)
+            GSTAMP_FLUSH
+            return;
+        }
 #pragma unroll
         for (int pass = 0; pass < 2; ++pass) {
 #pragma unroll
@@ -995,6 +1051,35 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(FastArgs g) {
     }
 }
 
+// EGOMI_EPI_SWIGLU_BWD, K-sliced tail rows: d(act) = sum of the slabs (rounded to bf16 as the whole tiles round it), combined with gate|up into
+// d(gate|up) in the same pass.  g.M / g.N = tail rows / hidden units; C, C2 already point at the first tail row.  8 units per thread.
+__global__ __launch_bounds__(256) void splitk_reduce_swiglu_bwd_kernel(FastArgs g) {
+    const long long total = (long long)g.M * g.N;
+    const int nq = g.N >> 3;
+    const long long items = (long long)g.M * nq;
+    const bf16_t* GU = reinterpret_cast<const bf16_t*>(g.C2);
+    bf16_t* DGU = reinterpret_cast<bf16_t*>(g.C);
+    for (long long it = (long long)blockIdx.x * 256 + threadIdx.x; it < items; it += (long long)gridDim.x * 256) {
+        const int m = (int)(it / nq), c = (int)(it % nq) * 8;
+        const long long e = (long long)m * g.N + c;
+        float d[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int s2 = 0; s2 < g.splitk; ++s2) {
+            const f32x4 x = *reinterpret_cast<const f32x4*>(g.ws + (long long)s2 * total + e);
+            const f32x4 y = *reinterpret_cast<const f32x4*>(g.ws + (long long)s2 * total + e + 4);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { d[r] += x[r]; d[4 + r] += y[r]; }
+        }
+        const int ci = ((c >> 5) << 6) + (c & 31);
+        float gv[8], uv[8], og[8], ou[8];
+        load8<bf16_t>(GU + (long long)m * g.ldc2 + ci, gv);
+        load8<bf16_t>(GU + (long long)m * g.ldc2 + ci + 32, uv);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) swiglu_bwd_elem(bf2f(f2bf(d[r])), gv[r], uv[r], og[r], ou[r]);
+        store8<bf16_t>(DGU + (long long)m * g.ldc + ci, og);
+        store8<bf16_t>(DGU + (long long)m * g.ldc + ci + 32, ou);
+    }
+}
+
 static bool fast_applicable(const egomi_gemm_desc* d) {
     if (d->ab_dtype != EGOMI_BF16 || d->a_layout != 0 || d->b_layout != 0) return false;
     if (d->batch > 1) return false;
@@ -1303,6 +1388,17 @@ static int launch_8phase(const egomi_gemm_desc* d, FastArgs& g, hipStream_t s, i
     if (t1) (void)hipEventRecord(t1, s);
     if (tp.rows && g.epi == 1 && g.tickets) g.tickets = nullptr;         // the fused SwiGLU epilogue wants the separate combine + tail pass below
     if (leave_slabs) return egomi_launch_status();                       // EGOMI_EPI_SLABS: the caller's next kernel sums the tail rows' slabs
+    if (tp.rows && g.epi == 3) {                                         // K-sliced tail rows of d(act): summed and turned into d(gate|up) in one pass
+        FastArgs r = g;
+        const long long row0 = (long long)g.full_tm * 256;
+        r.M = d->M - (int)row0; r.splitk = tp.s;
+        r.C = (char*)g.C + row0 * g.ldc * 2;
+        r.C2 = (char*)g.C2 + row0 * g.ldc2 * 2;
+        const long long total = (long long)r.M * (d->N / 8);
+        const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+        EGOMI_LAUNCH(splitk_reduce_swiglu_bwd_kernel, dim3(grid), dim3(256), 0, s, r);
+        return egomi_launch_status();
+    }
     if (tp.rows && !g.tickets) {
         FastArgs r = g;
         const long long row0 = (long long)g.full_tm * 256;
@@ -1366,9 +1462,11 @@ int egomi_gemm_fast_try(const egomi_gemm_desc* d0, hipStream_t s) {
     if (d->epilogue != EGOMI_EPI_NONE) {
         // fused epilogues live in the 256x256 per-tile kernel's plain-bf16 store path only: whole interleaved groups per wave
         // (N % 256 == 0), 16-B aligned rows, nothing else in the epilogue
-        const bool ok = d->epilogue == EGOMI_EPI_SWIGLU && tc == 8 && d->c_dtype == EGOMI_BF16 && d->C2 && d->N % 256 == 0 && !d->bias && !d->residual &&
-                        !d->accumulate && d->act == 0 && d->alpha == 1.0f && d->ldc % 8 == 0 && d->ldc2 % 8 == 0 && d->ldc2 >= d->N / 2 &&
-                        (((uintptr_t)d->C | (uintptr_t)d->C2) & 15) == 0 && (long long)d->M * d->lda < (1ll << 31) && (long long)d->N * d->ldb < (1ll << 31);
+        const bool common = tc == 8 && d->c_dtype == EGOMI_BF16 && d->C2 && !d->bias && !d->residual &&
+                            !d->accumulate && d->act == 0 && d->alpha == 1.0f && d->ldc % 8 == 0 && d->ldc2 % 8 == 0 &&
+                            (((uintptr_t)d->C | (uintptr_t)d->C2) & 15) == 0 && (long long)d->M * d->lda < (1ll << 31) && (long long)d->N * d->ldb < (1ll << 31);
+        const bool ok = common && ((d->epilogue == EGOMI_EPI_SWIGLU && d->N % 256 == 0 && d->ldc2 >= d->N / 2) ||
+                                   (d->epilogue == EGOMI_EPI_SWIGLU_BWD && d->N % 64 == 0 && d->ldc >= 2 * d->N && d->ldc2 >= 2 * d->N));
         if (!ok) return EGOMI_E_UNSUPPORTED;
         if (dl.ws_tickets_zeroed && dl.workspace) {
             if (dl.workspace_bytes > 4096) { dl.workspace = (char*)dl.workspace + 4096; dl.workspace_bytes -= 4096; }

@@ -669,19 +669,25 @@ class Engine:
         dx = ops.rmsnorm_bwd(d_hn, ctx["x_last"], w["model.norm.weight"], ctx["rstd_f"], dw=dw, out=ws.get("dx_a", (M, d), T))
         # frozen layers only: with trainable layers the wgrad products between a dgrad and its norm would reuse the slab area
         defer_b = self.use_tail_fuse and T == torch.bfloat16 and not self.any_layer_trainable
+        fuse_swiglu_bwd = self.use_fused_swiglu and T == torch.bfloat16 and self.gu_il and Fd % 64 == 0 and ops.gemm_kernel_id(M, Fd, d) == 2
         for l in reversed(range(L)):
             p = f"model.layers.{l}."
             lc = ctx["layers"][l]
             gu, qkv = lc["gu"], lc["qkv"]
             self._begin_direct(l)
             # ---- MLP
-            d_act = self._dgrad(dx, p + "mlp.down_proj.weight", ws.get("d_act", (M, Fd), T))
-            self._wgrad(p + "mlp.down_proj.weight", dx, lc["act"])
             dgu = ws.get("dgu", (M, 2 * Fd), T)
-            if self.prepared and l in self.wguT and self.gu_il:
-                ops.swiglu_il_bwd(d_act, gu, dgu)                               # gu / dgu in the interleaved-32 layout of the stacked weight
+            wt_down = self.wT.get(p + "mlp.down_proj.weight") if self.prepared else None
+            if fuse_swiglu_bwd and wt_down is not None and l in self.wguT:
+                # d(act) = dx . W_down never reaches memory: the GEMM epilogue reads gate|up and writes d(gate|up) (EGOMI_EPI_SWIGLU_BWD)
+                ops.mm(dx, wt_down, out=dgu, swiglu_bwd_gu=gu)
             else:
-                ops.swiglu_bwd(d_act, gu[:, :Fd], gu[:, Fd:], dgu[:, :Fd], dgu[:, Fd:])
+                d_act = self._dgrad(dx, p + "mlp.down_proj.weight", ws.get("d_act", (M, Fd), T))
+                if self.prepared and l in self.wguT and self.gu_il:
+                    ops.swiglu_il_bwd(d_act, gu, dgu)                           # gu / dgu in the interleaved-32 layout of the stacked weight
+                else:
+                    ops.swiglu_bwd(d_act, gu[:, :Fd], gu[:, Fd:], dgu[:, :Fd], dgu[:, Fd:])
+            self._wgrad(p + "mlp.down_proj.weight", dx, lc["act"])
             t_h2 = None
             if self.prepared and l in self.wguT:
                 if defer_b:

@@ -192,7 +192,7 @@ def _tail_workspace(device, nbytes=(4096 + 256 * 2 * 262144)):
 
 def gemm_raw(A, B, C, M, N, K, lda, ldb, ldc, a_layout=0, b_layout=0, bias=None, residual=None, ldr=0,
              act=0, alpha=1.0, accumulate=False, batch=1, batch_inner=1, strides=(0, 0, 0, 0, 0, 0), force_generic=False,
-             workspace=None, split_k=0, persistent=None, swiglu_out=None, slabs=False, count_only=False, defer_tail=False):
+             workspace=None, split_k=0, persistent=None, swiglu_out=None, slabs=False, count_only=False, defer_tail=False, swiglu_bwd_gu=None):
     """C = act(alpha*A.B + bias) + residual (+C).  A/B/C are tensors whose data_ptr() is the first
     element of the (first) operand; all strides in elements.  See include/egomi.h."""
     if A.dtype != B.dtype:
@@ -214,6 +214,10 @@ def gemm_raw(A, B, C, M, N, K, lda, ldb, ldc, a_layout=0, b_layout=0, bias=None,
     d.alpha, d.accumulate, d.act, d.force_generic = alpha, int(accumulate), act, int(force_generic)
     if swiglu_out is not None:                            # EGOMI_EPI_SWIGLU: C = interleaved-32 gate|up, swiglu_out [M, N/2] = silu(gate)*up
         d.epilogue, d.C2, d.ldc2 = 1, swiglu_out.data_ptr(), _ld(swiglu_out)
+    if swiglu_bwd_gu is not None:                         # EGOMI_EPI_SWIGLU_BWD: the product is d(act); C = d(gate|up) [M, 2N], C2 = gate|up [M, 2N] (interleaved-32)
+        if swiglu_out is not None or swiglu_bwd_gu.dtype != C.dtype:
+            raise TypeError("gemm: swiglu_bwd_gu excludes swiglu_out and must have the output dtype")
+        d.epilogue, d.C2, d.ldc2 = 3, swiglu_bwd_gu.data_ptr(), _ld(swiglu_bwd_gu)
     if workspace is None and M >= 1024 and batch <= 1:
         workspace = _tail_workspace(A.device)            # ticket words + fp32 slabs for the shared tiles of the 256x256 kernel
         if persistent is False:                          # A/B runs, tests: the non-persistent kernel + combine launch; its slabs must

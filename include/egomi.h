@@ -144,6 +144,10 @@ typedef struct egomi_gemm_desc {
      * (replaces the separate pass over C of HF LlamaMLP.forward, modeling_llama.py:174-176).  bf16 output, N % 256 == 0, no
      * bias / residual / activation / alpha / accumulate, products large enough for the 256x256 kernel
      * (egomi_gemm_kernel_id == 2); anything else returns EGOMI_E_UNSUPPORTED.
+     * EGOMI_EPI_SWIGLU_BWD: the product A.B^T [M,N] is d(act), the gradient of silu(gate)*up (the data gradient of down_proj); it is never
+     * stored.  C2 [M, 2N] (row stride ldc2) holds gate|up in the interleaved-32 layout (read), C [M, 2N] (row stride ldc) receives
+     * d(gate|up) in the same layout = what egomi_swiglu_il_bwd would write from the stored bf16 d(act), bit for bit (replaces autograd's
+     * backward of modeling_llama.py:174-176 and a round trip of d(act) through HBM).  bf16, N % 64 == 0, same restrictions as above.
      * EGOMI_EPI_SLABS: skinny split-K products (M <= 512, the single-token decode projections) leave their fp32 K-slice slabs
      * [slices][M][N] (row stride N) in `workspace` UNSUMMED and never touch C: the caller's next kernel (egomi_slabs_rmsnorm,
      * egomi_qkv_finish) sums them in slice order while doing its own work, which saves the combine pass and a round trip of the
@@ -155,6 +159,7 @@ typedef struct egomi_gemm_desc {
 #define EGOMI_EPI_NONE 0
 #define EGOMI_EPI_SWIGLU 1
 #define EGOMI_EPI_SLABS 2
+#define EGOMI_EPI_SWIGLU_BWD 3
 int egomi_gemm(const egomi_gemm_desc* desc, egomi_stream_t stream);
 /* which kernel egomi_gemm would run for this descriptor: 2 = 256x256 8-phase bf16 NT kernel (either form), 1 = 128x128 / 256x128 bf16
  * NT kernel, 0 = generic */

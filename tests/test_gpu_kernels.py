@@ -498,6 +498,36 @@ def test_gemm_swiglu_epilogue(ops, M, Fd, K):
         ops.mm(x, w, out=gu, swiglu_out=act, bias=torch.zeros(2 * Fd, dtype=torch.bfloat16, device="cuda"))
 
 
+@pytest.mark.parametrize("M,Fd,K", [(5536, 11008, 4096), (4500, 2880, 2048), (2304, 4096, 2112), (4100, 4160, 2048)])
+def test_gemm_swiglu_backward_epilogue(ops, M, Fd, K):
+    """EGOMI_EPI_SWIGLU_BWD: the down_proj data gradient dx . W_down with SwiGLU's backward in its epilogue — d(gate|up) equals
+    egomi_swiglu_il_bwd applied to the stored bf16 product, bit for bit (whole tiles, ragged M, a last column tile that is partly outside
+    (Fd % 256 != 0), K-sliced tail rows), d(act) is never written, and it is the right function of the operands; refused where the
+    256x256 kernel does not run."""
+    from egoscaler_amd import _lib
+    dx = rnd(M, K, dtype=torch.bfloat16, seed=61).cuda()
+    wt = rnd(Fd, K, dtype=torch.bfloat16, seed=62, scale=0.05).cuda()                 # W_down^T: [ffn, d]
+    gate, up = rnd(M, Fd, dtype=torch.bfloat16, seed=63), rnd(M, Fd, dtype=torch.bfloat16, seed=64)
+    gu = torch.stack([gate.view(M, Fd // 32, 32), up.view(M, Fd // 32, 32)], 2).reshape(M, 2 * Fd).contiguous().cuda()
+    assert ops.gemm_kernel_id(M, Fd, K) == 2
+    dact = ops.mm(dx, wt)
+    ref = ops.swiglu_il_bwd(dact, gu, torch.empty_like(gu))
+    dgu = torch.full((M, 2 * Fd), 7.0, dtype=torch.bfloat16, device="cuda")
+    ops.mm(dx, wt, out=dgu, swiglu_bwd_gu=gu)
+    assert torch.equal(dgu, ref)
+    d32 = dx.float() @ wt.float().t()
+    g32, u32 = gate.cuda().float(), up.cuda().float()
+    sg = torch.sigmoid(g32)
+    want_g, want_u = d32 * u32 * sg * (1 + g32 * (1 - sg)), d32 * g32 * sg
+    got = dgu.view(M, Fd // 32, 2, 32).float()
+    close(got[:, :, 0].reshape(M, Fd), want_g.cpu(), 3e-2)
+    close(got[:, :, 1].reshape(M, Fd), want_u.cpu(), 3e-2)
+    with pytest.raises(_lib.EgomiError):
+        ops.mm(dx[:64], wt, out=dgu[:64], swiglu_bwd_gu=gu[:64])                      # too small for the 256x256 kernel
+    with pytest.raises(_lib.EgomiError):
+        ops.mm(dx, wt, out=dgu, swiglu_bwd_gu=gu, accumulate=True)
+
+
 def _ref_attention(qkv, B, S, H, hd, scale, causal, km):
     x = qkv.float().view(B, S, 3, H, hd)
     q, k, v = x[:, :, 0].transpose(1, 2), x[:, :, 1].transpose(1, 2), x[:, :, 2].transpose(1, 2)
