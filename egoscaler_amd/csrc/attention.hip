@@ -179,6 +179,33 @@ __device__ __forceinline__ void store_rows_via_lds(char* wbuf, const f32x16 (&ac
     }
 }
 
+// HD = 64 (PointBERT blocks): the wave's 32 x 64 block through a 144-B-pitch strip, whole 128-B rows out, 16 B per lane; no RoPE
+__device__ __forceinline__ void store_rows_via_lds64(char* wbuf, const f32x16 (&acc)[2], const float mul, bf16_t* gbase, const long long ld,
+                                                     const int row0, const int nrows, const int lane) {
+    const int half = lane >> 5, rl = lane & 31;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            u32x2 w;
+            w[0] = (uint32_t)f2bf(acc[dt][4 * g] * mul) | ((uint32_t)f2bf(acc[dt][4 * g + 1] * mul) << 16);
+            w[1] = (uint32_t)f2bf(acc[dt][4 * g + 2] * mul) | ((uint32_t)f2bf(acc[dt][4 * g + 3] * mul) << 16);
+            *reinterpret_cast<u32x2*>(wbuf + rl * 144 + (32 * dt + 8 * g + 4 * half) * 2) = w;
+        }
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int r = it * 8 + (lane >> 3), ch = lane & 7;
+        const u32x4 v = *reinterpret_cast<const u32x4*>(wbuf + r * 144 + ch * 16);
+        if (row0 + r < nrows) *reinterpret_cast<u32x4*>(gbase + (long long)(row0 + r) * ld + ch * 8) = v;
+    }
+}
+template <int HD>
+__device__ __forceinline__ void store_rows_t(char* wbuf, const f32x16 (&acc)[HD / 32], const float mul, bf16_t* gbase, const long long ld,
+                                             const int row0, const int nrows, const int lane, const float* rcos = nullptr, const float* rsin = nullptr) {
+    if constexpr (HD == 128) store_rows_via_lds(wbuf, acc, mul, gbase, ld, row0, nrows, lane, rcos, rsin);
+    else store_rows_via_lds64(wbuf, acc, mul, gbase, ld, row0, nrows, lane);
+}
+
 #ifdef ATTN_STAMP
 // Timing stamps (debug builds only, -DATTN_STAMP; tools/debug/attn_stamp.py): wave 0 of every block accumulates s_memtime
 // deltas per segment of the forward loop and adds them to g_attn_stamp[] at the end.
@@ -707,11 +734,12 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(AttnArgs a) {
 // backward 1/2: dQ (and delta).  Same structure as the forward (query on the lane): per 32-key sub-tile
 //   X = K.Q^T, dP^T = V.dO^T, dS^T = P^T*(dP^T - delta), dQ^T += K^T.dS^T
 // =================================================================================================
-template <int OCC>
+template <int OCC, int HD = AT_HD>
 __global__ __launch_bounds__(256, OCC) void attn_bwd_dq_kernel(AttnArgs a) {
+    constexpr int TB = 64 * 2 * HD;                                   // bytes of one 64-row K or V tile (HD = 64: the PointBERT blocks' backward under --unfreeze_pc_encoder)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NST = OCC == 2 ? 2 : 3;                             // K|V stages: OCC 2 = two blocks per CU (64 KB each), else three stages for the lone wave per SIMD
-    char* sMask = smem + NST * 2 * 64 * 256;
+    char* sMask = smem + NST * 2 * TB;
     const int lane = threadIdx.x & 63, half = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     int rank, h, b;
@@ -719,10 +747,10 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_dq_kernel(AttnArgs a) {
     const int q0 = ((a.S + 127) / 128 - 1 - rank) * 128;             // causal: longest blocks are dispatched first
     const bool wave_dead = q0 + wave * 32 >= a.S;                     // ragged last block: no query in this wave
     const long long row_base = (long long)b * a.S;
-    const bf16_t* Q = a.q + row_base * a.ld_qkv + h * AT_HD;
-    const bf16_t* K = a.k + row_base * a.ld_qkv + h * AT_HD;
-    const bf16_t* V = a.v + row_base * a.ld_qkv + h * AT_HD;
-    const bf16_t* DO = a.dout + row_base * a.ld_o + h * AT_HD;
+    const bf16_t* Q = a.q + row_base * a.ld_qkv + h * HD;
+    const bf16_t* K = a.k + row_base * a.ld_qkv + h * HD;
+    const bf16_t* V = a.v + row_base * a.ld_qkv + h * HD;
+    const bf16_t* DO = a.dout + row_base * a.ld_o + h * HD;
     const int qi = q0 + wave * 32 + (lane & 31);
     const int qr = qi < a.S ? qi : a.S - 1;
     int last = q0 + 127 < a.S - 1 ? q0 + 127 : a.S - 1;
@@ -732,14 +760,14 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_dq_kernel(AttnArgs a) {
 #pragma unroll
     for (int i = 0; i < NST - 1; ++i) {
         const int ti = i < ntiles ? i : ntiles - 1;
-        tile_dma<64>(K, a.ld_qkv, ti * 64, a.S - 1, smem + i * (2 * 64 * 256), wave, lane);
-        tile_dma<64>(V, a.ld_qkv, ti * 64, a.S - 1, smem + i * (2 * 64 * 256) + 64 * 256, wave, lane);
+        tile_dma_t<64, HD>(K, a.ld_qkv, ti * 64, a.S - 1, smem + i * (2 * TB), wave, lane);
+        tile_dma_t<64, HD>(V, a.ld_qkv, ti * 64, a.S - 1, smem + i * (2 * TB) + TB, wave, lane);
     }
     uint8_t mv[AT_MASK_IT];
     mask_fetch(a, row_base, ntiles * 64, mv);
-    bf16x8 qf[8], dof[8];
+    bf16x8 qf[HD / 16], dof[HD / 16];
 #pragma unroll
-    for (int ks = 0; ks < 8; ++ks) {
+    for (int ks = 0; ks < HD / 16; ++ks) {
         qf[ks] = *reinterpret_cast<const bf16x8*>(Q + (long long)qr * a.ld_qkv + 16 * ks + 8 * half);
         dof[ks] = *reinterpret_cast<const bf16x8*>(DO + (long long)qr * a.ld_o + 16 * ks + 8 * half);
     }
@@ -749,9 +777,9 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_dq_kernel(AttnArgs a) {
     // Written out for the dK/dV kernel, which runs after this one on the same stream.
     float dlt = 0.f;
     {
-        const bf16_t* Orow = a.o + (row_base + qr) * a.ld_o + h * AT_HD;
+        const bf16_t* Orow = a.o + (row_base + qr) * a.ld_o + h * HD;
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
+        for (int ks = 0; ks < HD / 16; ++ks) {
             const bf16x8 of = *reinterpret_cast<const bf16x8*>(Orow + 16 * ks + 8 * half);
 #pragma unroll
             for (int e = 0; e < 8; ++e) dlt = fmaf((float)dof[ks][e], (float)of[e], dlt);
@@ -762,28 +790,27 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_dq_kernel(AttnArgs a) {
     const float sc2 = a.scale * 1.4426950408889634f;
     // ordinary loads are consumed before the first LDS-DMA is outstanding (see attn_fwd_kernel)
 #pragma unroll
-    for (int ks = 0; ks < 8; ++ks) asm volatile("" :: "v"(qf[ks]), "v"(dof[ks]));
+    for (int ks = 0; ks < HD / 16; ++ks) asm volatile("" :: "v"(qf[ks]), "v"(dof[ks]));
     asm volatile("" :: "v"(lse2), "v"(dlt));
     mask_commit(a, row_base, ntiles * 64, mv, sMask);                  // visible to the block after the loop's first barrier
-    f32x16 dq[4];
+    f32x16 dq[HD / 32];
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt)
+    for (int dt = 0; dt < HD / 32; ++dt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) dq[dt][r] = 0.f;
 
     int stg = 0;
     for (int t = 0; t < ntiles; ++t) {
         const int kv0 = t * 64;
-        char* sK = smem + stg * (2 * 64 * 256);
-        char* sV = sK + 64 * 256;
+        char* sK = smem + stg * (2 * TB);
+        char* sV = sK + TB;
         {
             const int t2 = t + NST - 1 < ntiles ? t + NST - 1 : ntiles - 1;
             const int s2 = stg >= 1 ? stg - 1 : NST - 1;               // (stg + NST - 1) % NST
-            char* nK = smem + s2 * (2 * 64 * 256);
-            tile_dma<64>(K, a.ld_qkv, t2 * 64, a.S - 1, nK, wave, lane);
-            tile_dma<64>(V, a.ld_qkv, t2 * 64, a.S - 1, nK + 64 * 256, wave, lane);
-            if (NST == 3) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");   // tile t landed; the later ones stay in flight
-            else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            char* nK = smem + s2 * (2 * TB);
+            tile_dma_t<64, HD>(K, a.ld_qkv, t2 * 64, a.S - 1, nK, wave, lane);
+            tile_dma_t<64, HD>(V, a.ld_qkv, t2 * 64, a.S - 1, nK + TB, wave, lane);
+            asm volatile("s_waitcnt vmcnt(%0)" :: "n"((NST - 1) * (HD / 16)) : "memory");   // tile t landed (HD / 16 DMAs per tile and wave); the later ones stay in flight
         }
         stg = stg == NST - 1 ? 0 : stg + 1;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -796,9 +823,9 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_dq_kernel(AttnArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) { x[r] = 0.f; dp[r] = 0.f; }
 #pragma unroll
-            for (int ks = 0; ks < 8; ++ks) {
-                x = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_row8(sK, 32 * sub + (lane & 31), 2 * ks + half), qf[ks], x, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_row8(sV, 32 * sub + (lane & 31), 2 * ks + half), dof[ks], dp, 0, 0, 0);
+            for (int ks = 0; ks < HD / 16; ++ks) {
+                x = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_row8_t<HD>(sK, 32 * sub + (lane & 31), 2 * ks + half), qf[ks], x, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_row8_t<HD>(sV, 32 * sub + (lane & 31), 2 * ks + half), dof[ks], dp, 0, 0, 0);
             }
             float ds[16];
             const bool interior = ((kmask >> (32 * sub)) & 0xFFFFFFFFull) == 0xFFFFFFFFull &&
@@ -819,8 +846,8 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_dq_kernel(AttnArgs a) {
             for (int s2 = 0; s2 < 2; ++s2) {
                 const bf16x8 db = pack8(&ds[8 * s2]);
 #pragma unroll
-                for (int dt = 0; dt < 4; ++dt)
-                    dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_tr8(sK, 32 * sub + 16 * s2, 32 * dt, lane), db, dq[dt], 0, 0, 0);
+                for (int dt = 0; dt < HD / 32; ++dt)
+                    dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_tr8_t<HD>(sK, 32 * sub + 16 * s2, 32 * dt, lane), db, dq[dt], 0, 0, 0);
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -828,8 +855,8 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_dq_kernel(AttnArgs a) {
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // the tail's redundant DMAs have landed ...
     __builtin_amdgcn_s_barrier();                                     // ... for every wave: the stages are free for the row exchange
-    store_rows_via_lds(smem + wave * AT_XBYTES, dq, a.scale, a.dq + row_base * a.ld_dqkv + h * AT_HD, a.ld_dqkv, q0 + wave * 32, a.S, lane,
-                       a.rope_cos, a.rope_sin);
+    store_rows_t<HD>(smem + wave * (HD == 128 ? AT_XBYTES : 32 * 144), dq, a.scale, a.dq + row_base * a.ld_dqkv + h * HD, a.ld_dqkv, q0 + wave * 32, a.S, lane,
+                     a.rope_cos, a.rope_sin);
 }
 
 // =================================================================================================
@@ -1040,8 +1067,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq2_kernel(AttnArgs a) {
 //   X = Q.K^T, dP = dO.V^T, P = exp2(sc2*X - lse2), dS = P*(dP - delta), dV^T += dO^T.P, dK^T += Q^T.dS
 // =================================================================================================
 #define DKV_STAGE (2 * 32 * 256 + 4 * 256)
-template <int OCC>
+template <int OCC, int HD = AT_HD>
 __global__ __launch_bounds__(256, OCC) void attn_bwd_dkdv_kernel(AttnArgs a) {
+    constexpr int QB = 32 * 2 * HD, STAGE = 2 * QB + 4 * 256;          // Q | dO tiles of 32 rows + LSE / delta pieces (HD = 128: DKV_STAGE)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, half = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1049,10 +1077,10 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_dkdv_kernel(AttnArgs a) {
     attn_block_map(a, rank, h, b);
     const int kb0 = rank * 128;                                       // causal: key block 0 sweeps the most queries and is dispatched first
     const long long row_base = (long long)b * a.S;
-    const bf16_t* Q = a.q + row_base * a.ld_qkv + h * AT_HD;
-    const bf16_t* K = a.k + row_base * a.ld_qkv + h * AT_HD;
-    const bf16_t* V = a.v + row_base * a.ld_qkv + h * AT_HD;
-    const bf16_t* DO = a.dout + row_base * a.ld_o + h * AT_HD;
+    const bf16_t* Q = a.q + row_base * a.ld_qkv + h * HD;
+    const bf16_t* K = a.k + row_base * a.ld_qkv + h * HD;
+    const bf16_t* V = a.v + row_base * a.ld_qkv + h * HD;
+    const bf16_t* DO = a.dout + row_base * a.ld_o + h * HD;
     const float* LSE = a.lse + ((long long)b * a.H + h) * a.S;
     const float* DEL = a.delta + ((long long)b * a.H + h) * a.S;
     const int kj = kb0 + wave * 32 + (lane & 31);                      // this lane's key
@@ -1063,24 +1091,24 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_dkdv_kernel(AttnArgs a) {
     // OCC 2 (two blocks per CU, <= 256 registers): two stages, and the block's 128 V rows live in LDS (32 KB, read per tile)
     // instead of 32 registers per lane; OCC 1: three stages, V fragments in registers
     constexpr int NST = OCC == 2 ? 2 : 3;
-    char* sVblk = smem + NST * DKV_STAGE;
-    bf16x8 kf[8], vf[OCC == 2 ? 1 : 8];
-    if (OCC == 2) tile_dma<128>(V, a.ld_qkv, kb0, a.S - 1, sVblk, wave, lane);
+    char* sVblk = smem + NST * STAGE;
+    bf16x8 kf[HD / 16], vf[OCC == 2 ? 1 : HD / 16];
+    if (OCC == 2) tile_dma_t<128, HD>(V, a.ld_qkv, kb0, a.S - 1, sVblk, wave, lane);
 #pragma unroll
-    for (int ks = 0; ks < 8; ++ks) {
+    for (int ks = 0; ks < HD / 16; ++ks) {
         kf[ks] = *reinterpret_cast<const bf16x8*>(K + (long long)kr * a.ld_qkv + 16 * ks + 8 * half);
         if (OCC != 2) vf[ks] = *reinterpret_cast<const bf16x8*>(V + (long long)kr * a.ld_qkv + 16 * ks + 8 * half);
     }
     // ordinary loads are consumed before the query-tile DMAs start (see attn_fwd_kernel)
 #pragma unroll
-    for (int ks = 0; ks < 8; ++ks) asm volatile("" :: "v"(kf[ks]));
+    for (int ks = 0; ks < HD / 16; ++ks) asm volatile("" :: "v"(kf[ks]));
     if (OCC != 2) {
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) asm volatile("" :: "v"(vf[ks]));
+        for (int ks = 0; ks < HD / 16; ++ks) asm volatile("" :: "v"(vf[ks]));
     }
-    f32x16 dk[4], dv[4];
+    f32x16 dk[HD / 32], dv[HD / 32];
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt)
+    for (int dt = 0; dt < HD / 32; ++dt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) { dk[dt][r] = 0.f; dv[dt][r] = 0.f; }
     const float sc2 = a.scale * 1.4426950408889634f;
@@ -1089,41 +1117,40 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_dkdv_kernel(AttnArgs a) {
 
     auto issue = [&](int qt, char* stage) {
         const int q0 = qt * 32;
-        tile_dma<32>(Q, a.ld_qkv, q0, a.S - 1, stage, wave, lane);
-        tile_dma<32>(DO, a.ld_o, q0, a.S - 1, stage + 32 * 256, wave, lane);
+        tile_dma_t<32, HD>(Q, a.ld_qkv, q0, a.S - 1, stage, wave, lane);
+        tile_dma_t<32, HD>(DO, a.ld_o, q0, a.S - 1, stage + QB, wave, lane);
         int qq = q0 + lane;                                            // 64 floats per DMA; only the first 32 are read
         qq = qq < a.S ? qq : a.S - 1;
         const float* src = (wave & 1) ? (DEL + qq) : (LSE + qq);
-        __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(stage + 2 * 32 * 256 + wave * 256), 4, 0, 0);
+        __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(stage + 2 * QB + wave * 256), 4, 0, 0);
     };
     // NST stages, NST-1 query tiles in flight; past the last tile the DMA re-loads it into a stage nobody reads any more,
     // which keeps the vmcnt arithmetic constant (5 DMAs per tile)
     if (qt0 < nq) {
 #pragma unroll
-        for (int i = 0; i < NST - 1; ++i) issue(qt0 + i < nq ? qt0 + i : nq - 1, smem + i * DKV_STAGE);
+        for (int i = 0; i < NST - 1; ++i) issue(qt0 + i < nq ? qt0 + i : nq - 1, smem + i * STAGE);
     }
     int stg = 0;
     for (int qt = qt0; qt < nq; ++qt) {
         const int q0 = qt * 32;
-        char* st = smem + stg * DKV_STAGE;
-        issue(qt + NST - 1 < nq ? qt + NST - 1 : nq - 1, smem + (stg >= 1 ? stg - 1 : NST - 1) * DKV_STAGE);
-        if (NST == 3) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");  // tile qt landed; (NST-1) x (2 + 2 + 1) DMAs stay in flight
-        else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        char* st = smem + stg * STAGE;
+        issue(qt + NST - 1 < nq ? qt + NST - 1 : nq - 1, smem + (stg >= 1 ? stg - 1 : NST - 1) * STAGE);
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"((NST - 1) * (HD / 32 + 1)) : "memory");  // tile qt landed; (NST-1) x (HD/64 + HD/64 + 1) DMAs stay in flight
         stg = stg == NST - 1 ? 0 : stg + 1;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         const char* sQ = st;
-        const char* sDO = st + 32 * 256;
-        const float* sL = reinterpret_cast<const float*>(st + 2 * 32 * 256);          // LSE of the 32 queries
+        const char* sDO = st + QB;
+        const float* sL = reinterpret_cast<const float*>(st + 2 * QB);          // LSE of the 32 queries
         const float* sD = sL + 64;                                                      // delta (wave 1's piece)
         f32x16 x, dp;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { x[r] = 0.f; dp[r] = 0.f; }
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
-            x = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_row8(sQ, lane & 31, 2 * ks + half), kf[ks], x, 0, 0, 0);
-            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_row8(sDO, lane & 31, 2 * ks + half),
-                                                         OCC == 2 ? lds_row8(sVblk, wave * 32 + (lane & 31), 2 * ks + half) : vf[OCC == 2 ? 0 : ks], dp, 0, 0, 0);
+        for (int ks = 0; ks < HD / 16; ++ks) {
+            x = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_row8_t<HD>(sQ, lane & 31, 2 * ks + half), kf[ks], x, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_row8_t<HD>(sDO, lane & 31, 2 * ks + half),
+                                                         OCC == 2 ? lds_row8_t<HD>(sVblk, wave * 32 + (lane & 31), 2 * ks + half) : vf[OCC == 2 ? 0 : ks], dp, 0, 0, 0);
         }
         float pv[16], ds[16];
         // masks only on edge tiles: every key of the wave visible, every query of the tile in range and (causal) not before any key
@@ -1156,9 +1183,9 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_dkdv_kernel(AttnArgs a) {
             const bf16x8 pb = pack8(&pv[8 * s2]);
             const bf16x8 db = pack8(&ds[8 * s2]);
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_tr8(sDO, 16 * s2, 32 * dt, lane), pb, dv[dt], 0, 0, 0);
-                dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_tr8(sQ, 16 * s2, 32 * dt, lane), db, dk[dt], 0, 0, 0);
+            for (int dt = 0; dt < HD / 32; ++dt) {
+                dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_tr8_t<HD>(sDO, 16 * s2, 32 * dt, lane), pb, dv[dt], 0, 0, 0);
+                dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_tr8_t<HD>(sQ, 16 * s2, 32 * dt, lane), db, dk[dt], 0, 0, 0);
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1166,9 +1193,9 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_dkdv_kernel(AttnArgs a) {
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    store_rows_via_lds(smem + wave * AT_XBYTES, dk, a.scale, a.dk + row_base * a.ld_dqkv + h * AT_HD, a.ld_dqkv, kb0 + wave * 32, a.S, lane,
-                       a.rope_cos, a.rope_sin);
-    store_rows_via_lds(smem + wave * AT_XBYTES, dv, 1.0f, a.dv + row_base * a.ld_dqkv + h * AT_HD, a.ld_dqkv, kb0 + wave * 32, a.S, lane);
+    store_rows_t<HD>(smem + wave * (HD == 128 ? AT_XBYTES : 32 * 144), dk, a.scale, a.dk + row_base * a.ld_dqkv + h * HD, a.ld_dqkv, kb0 + wave * 32, a.S, lane,
+                     a.rope_cos, a.rope_sin);
+    store_rows_t<HD>(smem + wave * (HD == 128 ? AT_XBYTES : 32 * 144), dv, 1.0f, a.dv + row_base * a.ld_dqkv + h * HD, a.ld_dqkv, kb0 + wave * 32, a.S, lane);
 }
 
 // =================================================================================================
@@ -1432,7 +1459,8 @@ extern "C" int egomi_attn_set_bwd_form(int form) {
 
 static int attn_check(const egomi_attn_desc* d, bool fwd_only = false) {
     if (!d || !d->q || !d->k || !d->v) return EGOMI_E_BADARG;
-    if (d->head_dim != AT_HD && !(fwd_only && d->head_dim == 64)) return EGOMI_E_UNSUPPORTED;
+    if (d->head_dim != AT_HD && d->head_dim != 64) return EGOMI_E_UNSUPPORTED;
+    (void)fwd_only;
     if (d->B <= 0 || d->H <= 0 || d->S <= 0) return EGOMI_E_SHAPE;
     if (d->dtype != EGOMI_BF16) return EGOMI_E_UNSUPPORTED;
     if (d->ld_qkv % 8 || d->ld_qkv < d->head_dim * d->H) return EGOMI_E_SHAPE;
@@ -1480,16 +1508,24 @@ extern "C" int egomi_attn_bwd(const egomi_attn_desc* d, egomi_stream_t stream) {
     const int rc = attn_check(d);
     if (rc) return rc;
     if (!d->o || !d->lse || !d->dout || !d->delta || !d->dq || !d->dk || !d->dv) return EGOMI_E_BADARG;
-    if (d->ld_o % 8 || d->ld_dqkv % 8 || d->ld_o < AT_HD * d->H || d->ld_dqkv < AT_HD * d->H) return EGOMI_E_SHAPE;
+    if (d->ld_o % 8 || d->ld_dqkv % 8 || d->ld_o < d->head_dim * d->H || d->ld_dqkv < d->head_dim * d->H) return EGOMI_E_SHAPE;
     if (((uintptr_t)d->dout & 15) || (((uintptr_t)d->dq | (uintptr_t)d->dk | (uintptr_t)d->dv) & 15) || ((uintptr_t)d->o & 15)) return EGOMI_E_SHAPE;
     if (d->S > AT_MAXS) return EGOMI_E_UNSUPPORTED;
     if ((d->rope_cos == nullptr) != (d->rope_sin == nullptr)) return EGOMI_E_BADARG;
     if (d->rope_cos && (((uintptr_t)d->rope_cos | (uintptr_t)d->rope_sin) & 15)) return EGOMI_E_SHAPE;
     AttnArgs a = attn_args(d);
     hipStream_t s = (hipStream_t)stream;
+    const dim3 grid((unsigned)(((d->S + 127) / 128) * d->H * d->B));
+    if (d->head_dim == 64) {
+        // the PointBERT blocks (point_encoder.py:30-55 under --unfreeze_pc_encoder): the first-form kernels at HD = 64, two blocks per CU; no RoPE
+        if (d->rope_cos) return EGOMI_E_UNSUPPORTED;
+        const size_t lq = 2 * 2 * 64 * 128 + (size_t)((d->S + 63) / 64) * 64, lk = 2 * (2 * 32 * 128 + 4 * 256) + 128 * 128;
+        EGOMI_LAUNCH((attn_bwd_dq_kernel<2, 64>), grid, dim3(256), lq, s, a);
+        EGOMI_LAUNCH((attn_bwd_dkdv_kernel<2, 64>), grid, dim3(256), lk, s, a);
+        return egomi_launch_status();
+    }
     const size_t lds_q = ((occ_dq2() ? 2 : 3) * 2 * 64 * 256) + (size_t)((d->S + 63) / 64) * 64;
     const int occ = attn_occ();
-    const dim3 grid((unsigned)(((d->S + 127) / 128) * d->H * d->B));
     const bool off32 = (long long)d->S * d->ld_qkv * 2 < (1ll << 32) && (long long)d->S * d->ld_o * 2 < (1ll << 32);     // the second forms address rows with 32-bit byte offsets
     if ((occ & 1) && attn_bwd_form() == 2 && off32) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q);

@@ -172,13 +172,21 @@ class PointBackboneTrainer:
         c.update(ph_pre=ph_pre, ph=ph, blocks=[])
         xf, posf = x.view(M, D), pos.view(M, D)
         scale = hd ** -0.5
+        fused = eng.use_fused_attention and T == torch.bfloat16 and hd == 64
         for i in range(pb.depth):
             p = f"{PRE}blocks.blocks.{i}."
             xs = torch.empty(M, D, dtype=T, device=dev)
             h = ops.layernorm(xf, w[p + "norm1.weight"], w[p + "norm1.bias"], pb.ln_eps, add=posf, sum_out=xs)
             qkv = ops.mm(h, w[p + "attn.qkv.weight"])
             ao = torch.empty(M, D, dtype=T, device=dev)
-            Pm = eng._attention(qkv, B, Pn, H, hd, ao, False, None, scale, True)
+            Pm = lse = None
+            if fused:
+                # fused flash-style kernels at head_dim 64 (csrc/attention.hip): the [B*H, S, S] probabilities never reach HBM; LSE and the
+                # output are kept for the backward kernels
+                lse = torch.empty(B, H, Pn, dtype=torch.float32, device=dev)
+                ops.attn_fwd(qkv, B, Pn, H, hd, scale, ao, lse, causal=False)
+            else:
+                Pm = eng._attention(qkv, B, Pn, H, hd, ao, False, None, scale, True)
             if drop is None:
                 x1 = ops.mm(ao, w[p + "attn.proj.weight"], bias=w[p + "attn.proj.bias"], residual=xs)
             else:
@@ -192,7 +200,7 @@ class PointBackboneTrainer:
             else:
                 br = ops.mm(m, w[p + "mlp.fc2.weight"], bias=w[p + "mlp.fc2.bias"])
                 xn = rowscale_add(x1, br, drop[i, 1], Pn)
-            c["blocks"].append(dict(xs=xs, h=h, qkv=qkv, P=Pm, ao=ao, x1=x1, h2n=h2n, m_pre=m_pre, m=m))
+            c["blocks"].append(dict(xs=xs, h=h, qkv=qkv, P=Pm, lse=lse, ao=ao, x1=x1, h2n=h2n, m_pre=m_pre, m=m))
             xf = xn
         out = ops.layernorm(xf, w[PRE + "norm.weight"], w[PRE + "norm.bias"], pb.ln_eps)
         c["x_last"] = xf
@@ -229,7 +237,11 @@ class PointBackboneTrainer:
             self._bg(p + "attn.proj.bias", db1)
             d_ao = self._dgrad(db1, w[PRE + p + "attn.proj.weight"])
             dqkv = torch.empty(M, 3 * D, dtype=T, device=dev)
-            eng._attention_bwd(bc["qkv"], bc["P"], d_ao, dqkv, B, Pn, H, hd, scale)
+            if bc["lse"] is not None:
+                ops.attn_bwd(bc["qkv"], bc["ao"], bc["lse"], d_ao, dqkv, eng.ws.get("pb_att_delta", (B, H, Pn), torch.float32), B, Pn, H, hd, scale,
+                             causal=False)
+            else:
+                eng._attention_bwd(bc["qkv"], bc["P"], d_ao, dqkv, B, Pn, H, hd, scale)
             self._wg(p + "attn.qkv.weight", dqkv, bc["h"])
             d_h = self._dgrad(dqkv, w[PRE + p + "attn.qkv.weight"])
             dx = layernorm_bwd(d_h, bc["xs"], w[PRE + p + "norm1.weight"], pb.ln_eps, dx_add=d_x1,

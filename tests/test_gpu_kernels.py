@@ -618,9 +618,11 @@ def test_fused_attention_forward_hd64(ops, B, S, H, causal, masked):
     assert torch.equal(out, out2)
 
 
-@pytest.mark.parametrize("B,S,H,causal,masked", [(2, 200, 3, True, True), (1, 692, 2, True, False), (2, 64, 1, False, True), (1, 33, 2, True, False), (1, 300, 1, True, True)])
-def test_fused_attention_backward(ops, B, S, H, causal, masked):
-    hd = 128
+@pytest.mark.parametrize("B,S,H,causal,masked,hd", [(2, 200, 3, True, True, 128), (1, 692, 2, True, False, 128), (2, 64, 1, False, True, 128),
+                                                       (1, 33, 2, True, False, 128), (1, 300, 1, True, True, 128),
+                                                       # head_dim 64: the PointBERT blocks under --unfreeze_pc_encoder (S = 513, 6 heads, no mask, not causal)
+                                                       (2, 513, 6, False, False, 64), (1, 200, 2, False, True, 64), (2, 33, 1, True, False, 64), (1, 130, 3, True, True, 64)])
+def test_fused_attention_backward(ops, B, S, H, causal, masked, hd):
     d = H * hd
     qkv = rnd(B * S, 3 * d, dtype=torch.bfloat16, seed=S + 1)
     dout = rnd(B * S, d, dtype=torch.bfloat16, seed=S + 2)

@@ -87,3 +87,44 @@ def test_unfrozen_point_backbone_trains_with_droppath():
     assert not torch.equal(before, m.state_dict()["model.point_backbone.blocks.blocks.1.mlp.fc1.weight"])
     sc = m.engine.pb_trainer.drop_scales(4)
     assert sc.shape == (dims.pb.depth, 2, 4) and float(sc[0].min()) == 1.0 and set(np.unique(sc[-1].cpu().numpy()).round(4)) <= {0.0, 1.25}
+
+
+def test_bf16_point_backbone_training_on_fused_head_dim_64_attention():
+    """--unfreeze_pc_encoder in bf16 with PointBERT heads of 64 (the real PointBERT-v1.2 has 6 x 64): the blocks run the fused attention forward
+    (LSE kept) and the fused head_dim-64 backward kernels instead of materialised [B*H, S, S] probabilities.  Against the same model on the
+    unfused path (bf16), and against the fp32 engine whose gradients the golden test above pins to the reference."""
+    dims = dims_tiny()
+    dims.pb.trans_dim, dims.pb.num_heads = 128, 2                    # head_dim 64; 33 tokens per cloud (ragged 32-row tiles)
+    dims.pb.projection_hidden_dim = [64, 96]
+    toks, masks, Lp = synth.synth_batch(dims, 4, text_len=8, num_steps=4, max_traj_token=40)
+    pts = torch.stack([synth.synth_cloud(dims, i) for i in range(4)])
+    start = [0, 5, 9, 2]
+    res = {}
+    for key, dtype, fused in (("fused", torch.bfloat16, True), ("unfused", torch.bfloat16, False), ("fp32", torch.float32, False)):
+        m = _model(dims, dtype)
+        m.train()
+        m.engine.use_fused_attention = fused
+        calls = []
+        from egoscaler_amd import ops
+        orig = ops.attn_bwd
+
+        def spy(*a, **k):
+            calls.append(a[9])                                           # head_dim
+            return orig(*a, **k)
+        ops.attn_bwd = spy
+        try:
+            loss = m.loss_and_backward(toks.cuda(), masks.cuda(), pts.cuda(), Lp, dims.tok.pad, fps_start=start)
+        finally:
+            ops.attn_bwd = orig
+        res[key] = (float(loss), {n: p.main_grad.float().clone() for n, p in m.named_parameters()
+                                  if n.startswith("model.point_backbone.blocks.") and getattr(p, "main_grad", None) is not None}, calls)
+    assert res["fused"][2].count(64) == dims.pb.depth and 64 not in res["unfused"][2]
+    assert abs(res["fused"][0] - res["fp32"][0]) < 2e-2 * abs(res["fp32"][0])
+    worst = 0.0
+    for n, g32 in res["fp32"][1].items():
+        scale = float(g32.abs().max()) + 1e-12
+        e_f = float((res["fused"][1][n] - g32).abs().max()) / scale
+        e_u = float((res["unfused"][1][n] - g32).abs().max()) / scale
+        worst = max(worst, e_f)
+        assert e_f <= max(2.0 * e_u, 5e-2), (n, e_f, e_u)                # as close to fp32 as the unfused bf16 path is
+    assert worst > 0
