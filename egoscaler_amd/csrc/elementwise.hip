@@ -654,22 +654,29 @@ extern "C" int egomi_softmax_bwd(const void* P, int64_t ld_p, const float* dP, i
 
 // ------------------------------------------------------------------------------------------------
 // A10  point-token splice.  reference: model/pointllm.py:131-171 (mm_use_point_start_end = True)
-// splice_scan: integer position logic (one block per sample).  err: 0 ok, 1 start/end count
-// mismatch (:146), 2 end token not at start+P+1 (:150), 3 more than one point segment in a sample
-// (the reference consumes consecutive clouds; this build supports one cloud per sample).
-// start_pos = -1 for a text-only sample (:137-142).
+// splice_scan: integer position logic (one block per sample), then one thread walks the batch like the reference's running
+// `cur_point_idx` (splice_clouds_kernel).  err: 0 ok, 1 start/end count mismatch (:146), 2 an end token not at start+P+1 (:150),
+// 4 the sample's cloud index is past the clouds given (:143 raises IndexError).
+// Several segments in one sample, AS THE REFERENCE TREATS THEM: `cur_point_features` is fetched once per sample (:143) and every pass of
+// the `for point_start_token_pos` loop rebuilds the row from the ORIGINAL embeddings (:155), so only the LAST segment is spliced — with the
+// cloud the sample started at — while cur_point_idx advances once per segment (:156) and shifts the clouds of the following samples.
+// start_pos = that last <point_start> (-1: text-only sample, :137-142, which advances the cloud index by one); cloud_idx[b] = index of the
+// cloud whose features the sample receives.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void splice_scan_kernel(const int64_t* ids, int S, int64_t patch_id, int64_t start_id, int64_t end_id, int P,
-                                                          int32_t* start_pos, int32_t* err) {
+                                                          int32_t* start_pos, int32_t* err, int32_t* nseg) {
     const int b = blockIdx.x;
     const int64_t* r = ids + (long long)b * S;
-    __shared__ int n_patch, n_start, n_end, first_start;
-    if (threadIdx.x == 0) { n_patch = 0; n_start = 0; n_end = 0; first_start = 0x7FFFFFFF; }
+    __shared__ int n_patch, n_start, n_end, last_start, bad_end;
+    if (threadIdx.x == 0) { n_patch = 0; n_start = 0; n_end = 0; last_start = -1; bad_end = 0; }
     __syncthreads();
     for (int s = threadIdx.x; s < S; s += 256) {
         const int64_t t = r[s];
         if (t == patch_id) atomicAdd(&n_patch, 1);
-        if (t == start_id) { atomicAdd(&n_start, 1); atomicMin(&first_start, s); }
+        if (t == start_id) {
+            atomicAdd(&n_start, 1); atomicMax(&last_start, s);
+            if (s + P + 1 >= S || r[s + P + 1] != end_id) atomicOr(&bad_end, 1);
+        }
         if (t == end_id) atomicAdd(&n_end, 1);
     }
     __syncthreads();
@@ -677,34 +684,43 @@ __global__ __launch_bounds__(256) void splice_scan_kernel(const int64_t* ids, in
         int e = 0, sp = -1;
         if (n_patch > 0) {
             if (n_start != n_end) e = 1;
-            else if (n_start > 1) e = 3;
-            else if (n_start == 1) {
-                sp = first_start;
-                if (sp + P + 1 >= S || r[sp + P + 1] != end_id) e = 2;
-            }
+            else if (bad_end) e = 2;
+            else if (n_start >= 1) sp = last_start;
         }
         start_pos[b] = e ? -1 : sp;
         err[b] = e;
+        nseg[b] = n_patch > 0 ? n_start : 1;
+    }
+}
+__global__ void splice_clouds_kernel(const int32_t* nseg, int B, int n_clouds, int32_t* start_pos, int32_t* err, int32_t* cloud_idx) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    int cur = 0;
+    for (int b = 0; b < B; ++b) {
+        const bool multimodal = !(nseg[b] == 1 && start_pos[b] < 0 && err[b] == 0);       // text-only samples never index the clouds
+        if (multimodal && cur >= n_clouds) { err[b] = 4; start_pos[b] = -1; }              // :143 comes before the token checks of the sample
+        cloud_idx[b] = cur < n_clouds ? cur : 0;
+        cur += nseg[b];
     }
 }
 
-extern "C" int egomi_splice_scan(const int64_t* ids, int B, int S, int64_t patch_id, int64_t start_id, int64_t end_id, int P,
-                                 int32_t* start_pos, int32_t* err, egomi_stream_t stream) {
-    if (!ids || !start_pos || !err) return EGOMI_E_BADARG;
-    if (B <= 0 || S <= 0 || P <= 0) return EGOMI_E_SHAPE;
-    EGOMI_LAUNCH(splice_scan_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, ids, S, patch_id, start_id, end_id, P, start_pos, err);
+extern "C" int egomi_splice_scan(const int64_t* ids, int B, int S, int64_t patch_id, int64_t start_id, int64_t end_id, int P, int n_clouds,
+                                 int32_t* start_pos, int32_t* err, int32_t* cloud_idx, int32_t* scratch, egomi_stream_t stream) {
+    if (!ids || !start_pos || !err || !cloud_idx || !scratch) return EGOMI_E_BADARG;
+    if (B <= 0 || S <= 0 || P <= 0 || n_clouds < 0) return EGOMI_E_SHAPE;
+    EGOMI_LAUNCH(splice_scan_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, ids, S, patch_id, start_id, end_id, P, start_pos, err, scratch);
+    EGOMI_LAUNCH(splice_clouds_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const int32_t*)scratch, B, n_clouds, start_pos, err, cloud_idx);
     return egomi_launch_status();
 }
 
 // out[b,s,:] = feats[b, s-start-1, :] if start < s <= start+P else W[ids[b,s], :]   (pointllm.py:107,155)
 template <typename T>
 __global__ __launch_bounds__(256) void embed_splice_fwd_kernel(const int64_t* ids, const T* W, const T* feats, const int32_t* start_pos,
-                                                               int S, int d, int P, int V, T* out) {
+                                                               const int32_t* cloud_idx, int S, int d, int P, int V, T* out) {
     const long long row = blockIdx.x;
     const int b = (int)(row / S), s = (int)(row % S);
     const int sp = (feats && start_pos) ? start_pos[b] : -1;
     const T* src;
-    if (sp >= 0 && s > sp && s <= sp + P) src = feats + ((long long)b * P + (s - sp - 1)) * d;
+    if (sp >= 0 && s > sp && s <= sp + P) src = feats + ((long long)(cloud_idx ? cloud_idx[b] : b) * P + (s - sp - 1)) * d;
     else {
         long long t = ids[row];
         if (t < 0 || t >= V) t = 0;                         // guarded on the host too
@@ -719,15 +735,15 @@ __global__ __launch_bounds__(256) void embed_splice_fwd_kernel(const int64_t* id
 
 // dW[ids] += dout (fp32 atomics, rows outside the point span); dfeats = dout rows inside the span
 template <typename T>
-__global__ __launch_bounds__(256) void embed_splice_bwd_kernel(const T* dout, const int64_t* ids, const int32_t* start_pos, int S, int d, int P,
-                                                               int V, float* dW, T* dfeats) {
+__global__ __launch_bounds__(256) void embed_splice_bwd_kernel(const T* dout, const int64_t* ids, const int32_t* start_pos, const int32_t* cloud_idx,
+                                                               int S, int d, int P, int V, float* dW, T* dfeats) {
     const long long row = blockIdx.x;
     const int b = (int)(row / S), s = (int)(row % S);
     const int sp = start_pos ? start_pos[b] : -1;
     const bool in_span = sp >= 0 && s > sp && s <= sp + P;
     if (in_span) {
         if (!dfeats) return;
-        T* dst = dfeats + ((long long)b * P + (s - sp - 1)) * d;
+        T* dst = dfeats + ((long long)(cloud_idx ? cloud_idx[b] : b) * P + (s - sp - 1)) * d;
         for (int c = threadIdx.x * 8; c < d; c += 256 * 8) {
             float v[8];
             load8<T>(dout + row * d + c, v);
@@ -740,21 +756,21 @@ __global__ __launch_bounds__(256) void embed_splice_bwd_kernel(const T* dout, co
     }
 }
 
-extern "C" int egomi_embed_splice_fwd(const int64_t* ids, const void* W, const void* feats, const int32_t* start_pos, int B, int S, int d,
-                                      int P, int V, void* out, int dtype, egomi_stream_t stream) {
+extern "C" int egomi_embed_splice_fwd(const int64_t* ids, const void* W, const void* feats, const int32_t* start_pos, const int32_t* cloud_idx,
+                                      int B, int S, int d, int P, int V, void* out, int dtype, egomi_stream_t stream) {
     if (!ids || !W || !out) return EGOMI_E_BADARG;
     if (B <= 0 || S <= 0 || d <= 0 || d % 8 || V <= 0) return EGOMI_E_SHAPE;
     EGOMI_DISPATCH_DTYPE(dtype, EGOMI_LAUNCH(embed_splice_fwd_kernel<T>, dim3(B * S), dim3(256), 0, (hipStream_t)stream,
-                                                   ids, (const T*)W, (const T*)feats, start_pos, S, d, P, V, (T*)out));
+                                                   ids, (const T*)W, (const T*)feats, start_pos, cloud_idx, S, d, P, V, (T*)out));
     return egomi_launch_status();
 }
 
-extern "C" int egomi_embed_splice_bwd(const void* dout, const int64_t* ids, const int32_t* start_pos, int B, int S, int d, int P, int V,
-                                      float* dW, void* dfeats, int dtype, egomi_stream_t stream) {
+extern "C" int egomi_embed_splice_bwd(const void* dout, const int64_t* ids, const int32_t* start_pos, const int32_t* cloud_idx, int B, int S, int d,
+                                      int P, int V, float* dW, void* dfeats, int dtype, egomi_stream_t stream) {
     if (!dout || !ids) return EGOMI_E_BADARG;
     if (B <= 0 || S <= 0 || d <= 0 || d % 8 || V <= 0) return EGOMI_E_SHAPE;
     EGOMI_DISPATCH_DTYPE(dtype, EGOMI_LAUNCH(embed_splice_bwd_kernel<T>, dim3(B * S), dim3(256), 0, (hipStream_t)stream,
-                                                   (const T*)dout, ids, start_pos, S, d, P, V, dW, (T*)dfeats));
+                                                   (const T*)dout, ids, start_pos, cloud_idx, S, d, P, V, dW, (T*)dfeats));
     return egomi_launch_status();
 }
 

@@ -381,7 +381,7 @@ class Engine:
         ctx = {"B": B, "S": S, "ids": input_ids, "layers": []} if save else None
         past = 0
         # ---- point branch (pointllm.py:112-129): only when S != 1 (prefill / training)
-        feats_proj, start_pos, pending_err = None, None, None
+        feats_proj, start_pos, pending_err, cloud_idx, Bc = None, None, None, None, 0
         if point_clouds is not None and S != 1:
             if isinstance(point_clouds, (list, tuple)):                          # pointllm.py:117-122
                 fl = [self.point_backbone(pc[None].to(self.device, torch.float32), [int(fps_start[i])]) for i, pc in enumerate(point_clouds)]
@@ -391,23 +391,25 @@ class Engine:
                 from .pointbert_train import PointBackboneTrainer
                 if self.pb_trainer is None:
                     self.pb_trainer = PointBackboneTrainer(self)
-                feats, pb_ctx = self.pb_trainer.forward(point_clouds.to(self.device, torch.float32), fps_start, self.pb_trainer.drop_scales(B))
+                feats, pb_ctx = self.pb_trainer.forward(point_clouds.to(self.device, torch.float32), fps_start,
+                                                        self.pb_trainer.drop_scales(point_clouds.shape[0]))
                 ctx["pb_ctx"] = pb_ctx
                 self.prepared_bn_stale = True
             else:
                 feats = self.point_backbone(point_clouds.to(self.device, torch.float32), fps_start)
-            fm = feats.reshape(B * Pn, pb.trans_dim)
+            Bc = feats.shape[0]                      # clouds given: one per sample in EgoScaler's data; the splice follows the reference's running
+            fm = feats.reshape(Bc * Pn, pb.trans_dim)   # cloud index, so a batch whose samples hold several segments may bring more (pointllm.py:135-156)
             acts = [fm]
             nh = len(pb.projection_hidden_dim)
             cur = fm
             for j in range(nh):                                                    # pointllm.py:67-81
                 Wj, bj = w[f"model.point_proj.{2 * j}.weight"], w[f"model.point_proj.{2 * j}.bias"]
-                pre_act = ops.mm(cur, Wj, bias=bj, out=ws.get(f"pp_pre{j}", (B * Pn, Wj.shape[0]), T))
-                cur = ops.gelu(pre_act, out=ws.get(f"pp_act{j}", (B * Pn, Wj.shape[0]), T))
+                pre_act = ops.mm(cur, Wj, bias=bj, out=ws.get(f"pp_pre{j}", (Bc * Pn, Wj.shape[0]), T))
+                cur = ops.gelu(pre_act, out=ws.get(f"pp_act{j}", (Bc * Pn, Wj.shape[0]), T))
                 acts += [pre_act, cur]
             Wl, bl = w[f"model.point_proj.{2 * nh}.weight"], w[f"model.point_proj.{2 * nh}.bias"]
-            feats_proj = ops.mm(cur, Wl, bias=bl, out=ws.get("pp_out", (B * Pn, d), T))
-            sp, err = ops.splice_scan(input_ids, tok, Pn)
+            feats_proj = ops.mm(cur, Wl, bias=bl, out=ws.get("pp_out", (Bc * Pn, d), T))
+            sp, err, cloud_idx = ops.splice_scan(input_ids, tok, Pn, Bc)
             # the reference checks the markers on the host right here (pointllm.py:137-151) and stalls the stream for it.  The
             # scan kernel already answers an inconsistent sample with start_pos = -1 (= text only: nothing downstream reads out
             # of range), so the verdict is copied to pinned memory now and looked at when the rest of the forward pass has been
@@ -417,10 +419,10 @@ class Engine:
             if save:
                 ctx["pp_acts"] = acts
         if save:
-            ctx["start_pos"] = start_pos
+            ctx["start_pos"], ctx["cloud_idx"], ctx["n_clouds"] = start_pos, cloud_idx, Bc
             ctx["has_points"] = feats_proj is not None
         x = ws.get("x_emb", (B, S, d), T) if not save else torch.empty(B, S, d, dtype=T, device=self.device)
-        ops.embed_splice(input_ids, w["model.embed_tokens.weight"], feats_proj, start_pos, Pn, out=x)
+        ops.embed_splice(input_ids, w["model.embed_tokens.weight"], feats_proj, start_pos, Pn, out=x, cloud_idx=cloud_idx)
         x = x.view(M, d)
         key_mask = None
         if attention_mask is not None:
@@ -548,7 +550,8 @@ class Engine:
                 raise ValueError("The number of point start tokens and point end tokens should be the same.")
             if code == 2:
                 raise ValueError("The point end token should follow the point start token.")
-            raise NotImplementedError("more than one point segment per sample is not supported by this build")
+            # pointllm.py:143 `point_features[cur_point_idx]`: the running cloud index (one per text-only sample, one per SEGMENT of the others) ran past the clouds
+            raise IndexError("index out of range: the batch's point segments need more point clouds than were given (pointllm.py:143,156)")
 
     def logits(self, hn, rows=None, padded=False):
         """lm_head (pointllm.py:227-228).  hn [M,d] -> [M,V].  padded=True (training step): the result is a view of a
@@ -735,9 +738,12 @@ class Engine:
         Pn = pb.point_token_len
         V = lm.vocab_size
         emb_name = "model.embed_tokens.weight"
-        d_feats = ws.get("d_pp_out", (B * Pn, d), T) if ctx["has_points"] else None
+        Bc = ctx["n_clouds"]
+        d_feats = ws.get("d_pp_out", (Bc * Pn, d), T) if ctx["has_points"] else None
+        if d_feats is not None:
+            d_feats.zero_()                                    # a cloud no sample received (text-only sample, skipped index) has a zero gradient
         ops.embed_splice_bwd(dx.view(B, S, d), ctx["ids"], ctx["start_pos"], Pn, V,
-                             self.grad_buffer(emb_name) if emb_name in tr else None, d_feats)
+                             self.grad_buffer(emb_name) if emb_name in tr else None, d_feats, cloud_idx=ctx["cloud_idx"])
         if ctx["has_points"]:
             acts = ctx["pp_acts"]
             nh = len(pb.projection_hidden_dim)
@@ -752,13 +758,13 @@ class Engine:
                         # dX = dY . W on the tuned K-contiguous kernel: the (trainable, hence changing) projector weight is
                         # transposed on the fly (a 16-MB pass) instead of running the transposing generic kernel (0.34 ms each)
                         wt = ops.transpose(w[Wn], out=ws.get(f"pp_wT{j}", (w[Wn].shape[1], w[Wn].shape[0]), T))
-                        g_in = ops.mm(g, wt, out=ws.get(f"d_pp_act{j}", (B * Pn, w[Wn].shape[1]), T))
+                        g_in = ops.mm(g, wt, out=ws.get(f"d_pp_act{j}", (Bc * Pn, w[Wn].shape[1]), T))
                     else:
-                        g_in = ops.mm(g, w[Wn], out=ws.get(f"d_pp_act{j}", (B * Pn, w[Wn].shape[1]), T), b_layout=1)
+                        g_in = ops.mm(g, w[Wn], out=ws.get(f"d_pp_act{j}", (Bc * Pn, w[Wn].shape[1]), T), b_layout=1)
                     g = ops.gelu_bwd(g_in, acts[2 * j - 1], out=ws.get(f"d_pp_pre{j}", g_in.shape, T))
                 elif ctx.get("pb_ctx") is not None:
                     d_backbone = ops.mm(g, w[Wn], b_layout=1)                  # gradient w.r.t. the PointBERT output
-                    self.pb_trainer.backward(d_backbone.view(B, Pn, pb.trans_dim), ctx["pb_ctx"])
+                    self.pb_trainer.backward(d_backbone.view(Bc, Pn, pb.trans_dim), ctx["pb_ctx"])
                     if self.grad_sync is not None:
                         for nm in self.trainable:
                             if nm.startswith("model.point_backbone."):

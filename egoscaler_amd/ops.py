@@ -436,25 +436,27 @@ def softmax_bwd(Pm, dP, dS, rows, Sk):
     return dS
 
 
-def splice_scan(ids, tok, Pn):
+def splice_scan(ids, tok, Pn, n_clouds=None):
+    """-> (start_pos, err, cloud_idx), int32 [B] each (include/egomi.h: the reference's position checks and its running cloud index)."""
     B, Sl = ids.shape
-    sp = torch.empty(B, dtype=torch.int32, device=ids.device)
-    err = torch.empty(B, dtype=torch.int32, device=ids.device)
-    call("egomi_splice_scan", P(ids), c_i(B), c_i(Sl), c_i64(tok.point_patch), c_i64(tok.point_start), c_i64(tok.point_end), c_i(Pn), P(sp), P(err), S())
-    return sp, err
+    sp, err, cloud, scratch = (torch.empty(B, dtype=torch.int32, device=ids.device) for _ in range(4))
+    call("egomi_splice_scan", P(ids), c_i(B), c_i(Sl), c_i64(tok.point_patch), c_i64(tok.point_start), c_i64(tok.point_end), c_i(Pn),
+         c_i(B if n_clouds is None else n_clouds), P(sp), P(err), P(cloud), P(scratch), S())
+    return sp, err, cloud
 
 
-def embed_splice(ids, W, feats, start_pos, Pn, out=None):
+def embed_splice(ids, W, feats, start_pos, Pn, out=None, cloud_idx=None):
     B, Sl = ids.shape
     V, d = W.shape
     out = torch.empty(B, Sl, d, dtype=W.dtype, device=W.device) if out is None else out
-    call("egomi_embed_splice_fwd", P(ids), P(W), P(feats), P(start_pos), c_i(B), c_i(Sl), c_i(d), c_i(Pn), c_i(V), P(out), c_i(dt(W.dtype)), S())
+    call("egomi_embed_splice_fwd", P(ids), P(W), P(feats), P(start_pos), P(cloud_idx), c_i(B), c_i(Sl), c_i(d), c_i(Pn), c_i(V), P(out), c_i(dt(W.dtype)), S())
     return out
 
 
-def embed_splice_bwd(dout, ids, start_pos, Pn, V, dW=None, dfeats=None):
+def embed_splice_bwd(dout, ids, start_pos, Pn, V, dW=None, dfeats=None, cloud_idx=None):
     B, Sl, d = dout.shape
-    call("egomi_embed_splice_bwd", P(dout), P(ids), P(start_pos), c_i(B), c_i(Sl), c_i(d), c_i(Pn), c_i(V), P(dW), P(dfeats), c_i(dt(dout.dtype)), S())
+    call("egomi_embed_splice_bwd", P(dout), P(ids), P(start_pos), P(cloud_idx), c_i(B), c_i(Sl), c_i(d), c_i(Pn), c_i(V), P(dW), P(dfeats),
+         c_i(dt(dout.dtype)), S())
 
 
 def cross_entropy(logits, targets, ignore_index, dlogits=None, grad_scale=1.0):

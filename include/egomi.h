@@ -375,18 +375,21 @@ int egomi_softmax_bwd(const void* P, int64_t ld_p, const float* dP, int64_t ld_d
                       int dtype, egomi_stream_t stream);
 
 /* A10  point-token splice.  replaces model/pointllm.py:131-171 (mm_use_point_start_end=True).
- * splice_scan: per sample start_pos = position of <point_start> (-1: text-only sample) and
- * err: 0 ok | 1 start/end count mismatch (:146) | 2 <point_end> not at start+P+1 (:150) |
- * 3 more than one point segment (unsupported here).
- * embed_splice_fwd: out[b,s] = feats[b, s-start-1] if start < s <= start+P else W[ids[b,s]]
+ * splice_scan: per sample start_pos = position of the <point_start> whose span receives the features (-1: text-only sample or
+ * error), cloud_idx = which of the n_clouds clouds it receives (the reference's running cur_point_idx, :135,143,156), and
+ * err: 0 ok | 1 start/end count mismatch (:146) | 2 a <point_end> not at start+P+1 (:150) | 4 cloud index past the clouds given
+ * (:143 IndexError).  A sample with several segments is treated as the reference treats it: only its LAST segment is spliced,
+ * with the cloud the sample started at, and the cloud index advances once per segment.  scratch: B int32.
+ * embed_splice_fwd: out[b,s] = feats[cloud_idx[b], s-start-1] if start < s <= start+P else W[ids[b,s]]
  * (embedding lookup :107 + torch.cat splice :155).  bwd: dW (fp32 [V,d]) += rows outside the span,
- * dfeats = rows inside it.  feats/start_pos/dW/dfeats may be NULL. */
-int egomi_splice_scan(const int64_t* ids, int B, int S, int64_t patch_id, int64_t start_id, int64_t end_id, int P,
-                      int32_t* start_pos, int32_t* err, egomi_stream_t stream);
-int egomi_embed_splice_fwd(const int64_t* ids, const void* W, const void* feats, const int32_t* start_pos, int B, int S, int d,
-                           int P, int V, void* out, int dtype, egomi_stream_t stream);
-int egomi_embed_splice_bwd(const void* dout, const int64_t* ids, const int32_t* start_pos, int B, int S, int d, int P, int V,
-                           float* dW, void* dfeats, int dtype, egomi_stream_t stream);
+ * dfeats[cloud_idx[b]] = rows inside it (rows of clouds no sample received are not written: zero them first).
+ * feats/start_pos/dW/dfeats may be NULL; cloud_idx NULL = cloud b for sample b. */
+int egomi_splice_scan(const int64_t* ids, int B, int S, int64_t patch_id, int64_t start_id, int64_t end_id, int P, int n_clouds,
+                      int32_t* start_pos, int32_t* err, int32_t* cloud_idx, int32_t* scratch, egomi_stream_t stream);
+int egomi_embed_splice_fwd(const int64_t* ids, const void* W, const void* feats, const int32_t* start_pos, const int32_t* cloud_idx,
+                           int B, int S, int d, int P, int V, void* out, int dtype, egomi_stream_t stream);
+int egomi_embed_splice_bwd(const void* dout, const int64_t* ids, const int32_t* start_pos, const int32_t* cloud_idx, int B, int S, int d,
+                           int P, int V, float* dW, void* dfeats, int dtype, egomi_stream_t stream);
 
 /* A12  cross-entropy with ignore_index, mean over kept rows.  replaces F.cross_entropy at
  * models/pointllm/train.py:174-181.  count must be zeroed, then ce_count, then ce_fwd_bwd:

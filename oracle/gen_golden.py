@@ -838,9 +838,91 @@ def gen_train_steps():
     RPL.cfg_from_yaml_file = orig_cfg
 
 
+def gen_multi_segment():
+    """Several point segments in one sample and more clouds than samples, through the reference's own splice loop (pointllm.py:131-171): sample 0
+    holds TWO segments, sample 1 is text only, sample 2 holds one segment -> the reference splices cloud 0 into the LAST segment of sample 0
+    (the first keeps its <point_patch> embeddings), skips clouds 1 and 2 and gives cloud 3 to sample 2; with only 3 clouds it raises IndexError.
+    Frozen-LLM flags, train mode: logits, loss, gradients of the projector / embedding / lm_head."""
+    import pointllm.model.pointllm as RPL
+    from pointllm.model import PointLLMLlamaForCausalLM, PointLLMConfig
+    import model_arch as RMA
+    dims = dims_tiny()
+    lm, pb, tok = dims.lm, dims.pb, dims.tok
+    orig_cfg = RPL.cfg_from_yaml_file
+    RPL.cfg_from_yaml_file = lambda path: _pb_cfg(pb) if os.path.basename(path) == "tiny.yaml" else orig_cfg(path)
+    cfg = PointLLMConfig(hidden_size=lm.hidden_size, intermediate_size=lm.intermediate_size,
+                         num_hidden_layers=lm.num_hidden_layers, num_attention_heads=lm.num_attention_heads,
+                         num_key_value_heads=lm.num_attention_heads, vocab_size=lm.vocab_size,
+                         rms_norm_eps=lm.rms_norm_eps, max_position_embeddings=lm.max_position_embeddings,
+                         pad_token_id=tok.pad, bos_token_id=tok.bos, eos_token_id=tok.eos,
+                         point_backbone="PointBERT", point_backbone_config_name="tiny", use_color=True,
+                         mm_use_point_start_end=True, DEFAULT_POINT_PATCH_TOKEN="<point_patch>",
+                         DEFAULT_POINT_START_TOKEN="<point_start>", DEFAULT_POINT_END_TOKEN="<point_end>",
+                         tie_word_embeddings=False, attn_implementation="eager")
+    base = PointLLMLlamaForCausalLM(cfg)
+    sd = synth.synth_state_dict(dims, 0)
+    base.load_state_dict(sd, strict=True)
+    tmp = tempfile.mkdtemp()
+    base.save_pretrained(tmp)
+    args = types.SimpleNamespace(unfreeze_pc_encoder=False, unfreeze_language_model=False, model_name=tmp, num_bins=tok.num_bins)
+    model = RMA.TrajPointLLMForCausalLM(args, cfg, tmp)
+    model.load_state_dict(sd, strict=True)
+    model.get_model().point_backbone_config.update(point_patch_token=tok.point_patch, point_start_token=tok.point_start, point_end_token=tok.point_end)
+
+    P = pb.point_token_len
+    g = np.random.default_rng(77)
+    seg = [tok.point_start] + [tok.point_patch] * P + [tok.point_end]
+    words = lambda n: g.integers(3, tok.point_patch, size=n).tolist()                                   # noqa: E731
+    rows = [[tok.bos] + words(3) + seg + words(4) + seg + words(6),
+            [tok.bos] + words(20),
+            [tok.bos] + words(5) + seg + words(9)]
+    S = max(len(r) for r in rows) + 2
+    toks = torch.full((3, S), tok.pad, dtype=torch.long)
+    masks = torch.zeros(3, S, dtype=torch.bool)
+    for i, r in enumerate(rows):
+        toks[i, :len(r)] = torch.tensor(r)
+        masks[i, :len(r)] = True
+    Lp = 6
+    pts = torch.stack([synth.synth_cloud(dims, 10 + i) for i in range(4)])
+    start = np.array([3, 0, 11, 7])
+    model.train()
+    with fixed_fps_start(start):
+        logits = model(input_ids=toks, attention_mask=masks, point_clouds=pts, return_dict=True).logits
+    loss = F.cross_entropy(logits[:, Lp - 1:-1, :].reshape(-1, logits.shape[-1]), toks[:, Lp:].flatten(), ignore_index=tok.pad)
+    loss.backward()
+    grads = {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+    out = {"tokens": toks.numpy(), "masks": masks.numpy(), "prompt_len": np.array(Lp), "fps_start": start, "logits": logits.detach().numpy(),
+           "loss": np.array(float(loss))}
+    for n in ("model.point_proj.0.weight", "model.point_proj.4.weight", "model.point_proj.4.bias", "model.embed_tokens.weight", "lm_head.weight"):
+        out["grad:" + n] = grads[n].numpy()
+    # the oracle's restatement of the same loop
+    sd_o = {k: v.clone().requires_grad_(k in ("model.point_proj.4.weight", "model.embed_tokens.weight")) for k, v in sd.items()}
+    lo = OPL.forward(sd_o, dims, toks, masks, pts, start)
+    loss_o = OL.traj_loss(lo, toks, Lp, tok.pad)
+    loss_o.backward()
+    print("multi_segment: logits rel", rel(lo.detach(), logits.detach()), " loss", float(loss), float(loss_o),
+          " grads rel", rel(sd_o["model.point_proj.4.weight"].grad, grads["model.point_proj.4.weight"]),
+          rel(sd_o["model.embed_tokens.weight"].grad, grads["model.embed_tokens.weight"]))
+    # one cloud too few: the running index of sample 2 is 3
+    raised = {}
+    for name, fn in (("reference", lambda: model(input_ids=toks, attention_mask=masks, point_clouds=pts[:3], return_dict=True)),
+                     ("oracle", lambda: OPL.forward(sd, dims, toks, masks, pts[:3], start[:3]))):
+        try:
+            with fixed_fps_start(start[:3]), torch.no_grad():
+                fn()
+            raised[name] = "none"
+        except Exception as e:                                                                         # noqa: BLE001
+            raised[name] = type(e).__name__
+    print("   3 clouds for a running index of 3:", raised)
+    assert raised["reference"] == raised["oracle"] == "IndexError"
+    out["err_too_few_clouds"] = np.array(raised["reference"])
+    np.savez_compressed(os.path.join(GOLD, "multi_segment.npz"), **out)
+    RPL.cfg_from_yaml_file = orig_cfg
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["pointcloud", "depth_cloud", "traj", "collate", "pointbert_full", "tiny_model", "tiny_pc_unfrozen", "tiny_model_bf16", "tiny_trained",
-                             "sampling", "train_steps"]
+                             "sampling", "train_steps", "multi_segment"]
     for w in which:
         globals()["gen_" + w]()
     sizes = {f: os.path.getsize(os.path.join(GOLD, f)) for f in sorted(os.listdir(GOLD))}

@@ -36,21 +36,30 @@ def splice_positions(input_ids: torch.Tensor, tok, P: int):
 
 
 def splice(input_ids, inputs_embeds, point_features, tok, P):
-    """embeds[:s+1] ++ point_features ++ embeds[s+P+1:]  (pointllm.py:155).  One cloud per sample,
-    consumed in batch order (cur_point_idx, :135,156)."""
-    pos = splice_positions(input_ids, tok, P)
+    """pointllm.py:131-171 for mm_use_point_start_end=True, statement by statement — including what it does with several segments in one
+    sample: the sample's features are fetched ONCE (`point_features[cur_point_idx]`, :143, IndexError past the clouds given — before the
+    sample's token checks), every pass of the `for point_start_token_pos` loop rebuilds the row from the ORIGINAL embeddings (:155), so only the
+    LAST segment is spliced, and cur_point_idx advances once per segment (:156); a sample without patch tokens advances it by one (:137-142)."""
     rows = []
     cur = 0
-    for b, starts in enumerate(pos):
-        e = inputs_embeds[b]
-        if not starts:
+    for b in range(input_ids.shape[0]):
+        ids, e = input_ids[b], inputs_embeds[b]
+        if (ids == tok.point_patch).sum() == 0:                                # :137 text-only sample
             rows.append(e)
             cur += 1
             continue
-        for s in starts:
-            e = torch.cat((e[:s + 1], point_features[cur], e[s + P + 1:]), dim=0)
-            cur += 1
-        rows.append(e)
+        feats = point_features[cur]                                            # :143
+        if (ids == tok.point_start).sum() != (ids == tok.point_end).sum():     # :146
+            raise ValueError("The number of point start tokens and point end tokens should be the same.")
+        new = None
+        for s in torch.where(ids == tok.point_start)[0].tolist():
+            if s + P + 1 >= ids.shape[0] or ids[s + P + 1] != tok.point_end:   # :150 (past the end the reference raises IndexError; not restated)
+                raise ValueError("The point end token should follow the point start token.")
+            new = torch.cat((e[:s + 1], feats, e[s + P + 1:]), dim=0)          # :155
+            cur += 1                                                           # :156
+        if new is None:
+            raise NotImplementedError("patch tokens without a <point_start>: the reference appends a stale / unbound variable here (:157)")
+        rows.append(new)
     return torch.stack(rows, 0)
 
 

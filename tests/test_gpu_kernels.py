@@ -195,10 +195,10 @@ def test_embed_splice_forward_backward_and_errors(ops, dtype):
     ids, _, _ = synth.synth_batch(dims, 3, text_len=8, num_steps=4, max_traj_token=40)
     ids[2, (ids[2] >= tok.point_patch) & (ids[2] <= tok.point_end)] = 9          # text-only sample
     W, feats = rnd(V, d, dtype=dtype), rnd(3, Pn, d, dtype=dtype, seed=1)
-    sp, err = ops.splice_scan(ids.cuda(), tok, Pn)
+    sp, err, cloud = ops.splice_scan(ids.cuda(), tok, Pn)
     ref_pos = OPL.splice_positions(ids, tok, Pn)
-    assert err.cpu().tolist() == [0, 0, 0] and sp.cpu().tolist() == [p[0] if p else -1 for p in ref_pos]
-    out = ops.embed_splice(ids.cuda(), W.cuda(), feats.cuda(), sp, Pn)
+    assert err.cpu().tolist() == [0, 0, 0] and sp.cpu().tolist() == [p[0] if p else -1 for p in ref_pos] and cloud.cpu().tolist() == [0, 1, 2]
+    out = ops.embed_splice(ids.cuda(), W.cuda(), feats.cuda(), sp, Pn, cloud_idx=cloud)
     ref = OPL.splice(ids, F.embedding(ids, W), feats, tok, Pn)
     assert torch.equal(out.cpu(), ref), "splice is a pure copy: must be bit-exact"
     dout = rnd(3, ids.shape[1], d, dtype=dtype, seed=2)
@@ -206,15 +206,32 @@ def test_embed_splice_forward_backward_and_errors(ops, dtype):
     OPL.splice(ids, F.embedding(ids, Wf), ff, tok, Pn).backward(dout.float())
     dW = torch.zeros(V, d, dtype=torch.float32, device="cuda")
     df = torch.zeros(3, Pn, d, dtype=dtype, device="cuda")
-    ops.embed_splice_bwd(dout.cuda(), ids.cuda(), sp, Pn, V, dW, df)
+    ops.embed_splice_bwd(dout.cuda(), ids.cuda(), sp, Pn, V, dW, df, cloud_idx=cloud)
     close(dW, Wf.grad, 1e-5)
     close(df, ff.grad, 1e-6)
     bad = ids.clone()
     bad[0, (bad[0] == tok.point_end).nonzero()[0, 0]] = 5            # count mismatch (pointllm.py:146)
     bad[1, (bad[1] == tok.point_end).nonzero()[0, 0]] = 5
     bad[1, -1] = tok.point_end                                       # end token in the wrong place (:150)
-    _, err = ops.splice_scan(bad.cuda(), tok, Pn)
+    _, err, _ = ops.splice_scan(bad.cuda(), tok, Pn)
     assert err.cpu().tolist() == [1, 2, 0]
+    # several segments in a sample (the reference's running cloud index, pointllm.py:135-156): sample 0 = [seg, seg], sample 1 text only,
+    # sample 2 = [seg] -> last segment of sample 0 gets cloud 0, sample 2 gets cloud 3; with 3 clouds sample 2 is an IndexError (code 4)
+    seg = [tok.point_start] + [tok.point_patch] * Pn + [tok.point_end]
+    rows = [[1, 7] + seg + [8, 9] + seg + [10], [1] + [11] * 30, [1, 12, 13] + seg + [14]]
+    Sm = max(len(r) for r in rows)
+    mids = torch.zeros(3, Sm, dtype=torch.long)
+    for i, r in enumerate(rows):
+        mids[i, :len(r)] = torch.tensor(r)
+    sp, err, cloud = ops.splice_scan(mids.cuda(), tok, Pn, 4)
+    assert err.cpu().tolist() == [0, 0, 0] and sp.cpu().tolist() == [2 + len(seg) + 2, -1, 3] and cloud.cpu().tolist() == [0, 2, 3]
+    feats4 = rnd(4, Pn, d, dtype=dtype, seed=4)
+    out = ops.embed_splice(mids.cuda(), W.cuda(), feats4.cuda(), sp, Pn, cloud_idx=cloud)
+    assert torch.equal(out.cpu(), OPL.splice(mids, F.embedding(mids, W), feats4, tok, Pn))
+    sp, err, cloud = ops.splice_scan(mids.cuda(), tok, Pn, 3)
+    assert err.cpu().tolist() == [0, 0, 4] and sp.cpu().tolist()[2] == -1
+    with pytest.raises(IndexError):
+        OPL.splice(mids, F.embedding(mids, W), feats4[:3], tok, Pn)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])

@@ -140,6 +140,32 @@ def test_splice_errors_raise_like_reference(tiny):
     assert str(e.value) == str(g["err_missing_end"])
 
 
+def test_several_segments_per_sample_match_the_reference(golden_dir):
+    """tests/golden/multi_segment.npz, recorded from the reference's own splice loop (pointllm.py:131-171): a sample with two segments (only the
+    last is spliced, with the cloud the sample started at), a text-only sample, and a sample that receives cloud 3 of 4 because the running
+    cloud index advanced once per segment.  Forward logits, loss and gradients (projector, embedding incl. the un-spliced <point_patch> row,
+    lm_head); one cloud too few raises IndexError like the reference."""
+    g = np.load(os.path.join(golden_dir, "multi_segment.npz"))
+    dims = dims_tiny()
+    m = make_model(dims, False)
+    m.train()
+    toks, masks, Lp = torch.from_numpy(g["tokens"]), torch.from_numpy(g["masks"]), int(g["prompt_len"])
+    pts = torch.stack([synth.synth_cloud(dims, 10 + i) for i in range(4)])
+    with torch.no_grad():
+        lg = m(input_ids=toks.cuda(), attention_mask=masks.cuda(), point_clouds=pts.cuda(), fps_start=g["fps_start"]).logits
+    assert rel(lg, g["logits"]) < REL
+    loss = m.loss_and_backward(toks.cuda(), masks.cuda(), pts.cuda(), Lp, dims.tok.pad, fps_start=g["fps_start"])
+    assert abs(float(loss) - float(g["loss"])) < REL * abs(float(g["loss"]))
+    params = dict(m.named_parameters())
+    for k in g.files:
+        if k.startswith("grad:"):
+            assert rel(params[k[5:]].main_grad, g[k]) < REL, k
+    assert float(params["model.embed_tokens.weight"].main_grad[dims.tok.point_patch].abs().max()) > 0
+    # a second step with the ordinary one-cloud-per-sample batch on the same engine: nothing of the 4-cloud step lingers
+    with pytest.raises(IndexError), torch.no_grad():
+        m(input_ids=toks.cuda(), attention_mask=masks.cuda(), point_clouds=pts[:3].cuda(), fps_start=g["fps_start"][:3])
+
+
 def test_pointbert_full_size_features(golden_dir):
     g = np.load(os.path.join(golden_dir, "pointbert_full.npz"))
     dims = dims_7b()

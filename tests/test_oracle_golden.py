@@ -156,6 +156,32 @@ def test_splice_errors(golden_dir):
     assert OPL.splice_positions(txt, dims.tok, dims.pb.point_token_len)[1] == []
 
 
+def test_several_segments_per_sample_as_the_reference_treats_them(golden_dir):
+    """multi_segment.npz (oracle/gen_golden.py gen_multi_segment, recorded from the reference's own loop, pointllm.py:131-171): two segments
+    in sample 0 (only the LAST one spliced, with cloud 0), a text-only sample, one segment in sample 2 (cloud 3 of 4: the running cloud
+    index advanced once per segment and once for the text-only sample); one cloud too few -> IndexError."""
+    g = _load(golden_dir, "multi_segment.npz")
+    dims = dims_tiny()
+    sd = synth.synth_state_dict(dims, 0)
+    watch = [k[5:] for k in g.files if k.startswith("grad:")]
+    sd = {k: v.clone().requires_grad_(k in watch) for k, v in sd.items()}
+    toks, masks, Lp = torch.from_numpy(g["tokens"]), torch.from_numpy(g["masks"]), int(g["prompt_len"])
+    pts = torch.stack([synth.synth_cloud(dims, 10 + i) for i in range(4)])
+    logits = OPL.forward(sd, dims, toks, masks, pts, g["fps_start"])
+    np.testing.assert_allclose(logits.detach().numpy(), g["logits"], rtol=0, atol=1e-5)
+    loss = OL.traj_loss(logits, toks, Lp, dims.tok.pad)
+    assert abs(float(loss) - float(g["loss"])) < 1e-6
+    loss.backward()
+    for n in watch:
+        ref = g["grad:" + n]
+        np.testing.assert_allclose(sd[n].grad.numpy(), ref, rtol=0, atol=1e-6 + 1e-4 * np.abs(ref).max())
+    # the first segment of sample 0 kept its <point_patch> embeddings: the embedding row of that token has a gradient
+    assert np.abs(g["grad:model.embed_tokens.weight"][dims.tok.point_patch]).max() > 0
+    with pytest.raises(IndexError), torch.no_grad():
+        OPL.forward(sd, dims, toks, masks, pts[:3], g["fps_start"][:3])
+    assert str(g["err_too_few_clouds"]) == "IndexError"
+
+
 def test_depth_to_cloud_oracle_vs_golden_and_pillow(golden_dir):
     """N4 oracle: (1) equals the fixture recorded from the reference's get_depth (depth.py:35-62); (2) its index walk equals
     Pillow's NEAREST resize itself on random size pairs (Pillow is the third-party library the reference calls, depth.py:50)."""
