@@ -50,6 +50,24 @@ def check(rc: int, what: str):
         raise EgomiError(f"{what}: egomi error {rc} ({msg})")
 
 
+_SYNC_DEBUG = os.environ.get("EGOMI_SYNC_DEBUG")     # debug aid: a file; every library call is followed by a device synchronisation, and the first call
+                                                      # after which the device reports an error is written there with its Python stack (a fault pinned to its launch)
+
+
 def call(name: str, *args):
     fn = getattr(lib(), name)
-    check(fn(*args), name)
+    if not _SYNC_DEBUG:
+        check(fn(*args), name)
+        return
+    import traceback
+    import torch
+    try:
+        check(fn(*args), name)
+        if not torch.cuda.is_current_stream_capturing():
+            torch.cuda.synchronize()
+    except BaseException as e:                                        # noqa: BLE001
+        with open(_SYNC_DEBUG, "a") as f:
+            f.write(f"=== {name} raised {type(e).__name__}: {str(e)[:200]}\n")
+            f.write("".join(traceback.format_stack(limit=14)))
+            f.write(f"args: {[getattr(a, 'value', a) for a in args]}\n")
+        raise

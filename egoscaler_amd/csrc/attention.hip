@@ -1332,7 +1332,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv2_kernel(AttnArgs a) {
             qo[j] = (uint32_t)((long long)r * a.ld_qkv + ch * 8) * 2u;
             dofs[j] = (uint32_t)((long long)r * a.ld_o + ch * 8) * 2u;
         }
-        int qq = q0 + lane;
+        // 64 lanes fetch 64 floats, the tile reads the first 32: lanes 32..63 repeat them.  (With q0 + lane the offsets advanced per tile ran
+        // 32 floats past the tile, and at S % 32 == 0 — no clamped last tile — the last (b, h) pair's last tile read 128 B past the END of the
+        // LSE / delta arrays: a page fault whenever such an array closed a mapped segment; S = 256 was the first such S in the suite.)
+        int qq = q0 + (lane & 31);
         qq = qq < a.S ? qq : a.S - 1;
         lo = (uint32_t)qq * 4u;
     };

@@ -35,3 +35,61 @@ def _release_cached_device_memory(request):
                 f.write(f"{request.module.__name__} reserved_after_empty={torch.cuda.memory_reserved() >> 20} MiB "
                         f"peak_reserved={torch.cuda.max_memory_reserved() >> 20} MiB\n")
             torch.cuda.reset_peak_memory_stats()
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _native_backtrace_on_abort():
+    """EGOMI_ABORT_TRACE=1: SIGABRT prints the native stack of the aborting thread (tools/debug/abort_trace.c) before pytest's faulthandler dump."""
+    if os.environ.get("EGOMI_ABORT_TRACE") == "1":
+        import ctypes
+        import subprocess
+        import tempfile
+        so = os.path.join(tempfile.mkdtemp(), "abort_trace.so")
+        subprocess.check_call(["gcc", "-shared", "-fPIC", "-O1", "-o", so, os.path.join(ROOT, "tools", "debug", "abort_trace.c")])
+        lib = ctypes.CDLL(so)
+        lib.install_abort_trace()
+        _ABORT_TRACE.append(lib)
+    yield
+
+
+_ABORT_TRACE = []
+
+
+@pytest.fixture(autouse=True)
+def _native_backtrace_on_abort_stays_installed():
+    if _ABORT_TRACE:
+        _ABORT_TRACE[0].install_abort_trace()          # (something re-registers SIGABRT during the suite)
+    yield
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _trace_device_allocations(request):
+    """EGOMI_ALLOC_TRACE=<file>: inside test_gpu_train_modes / test_gpu_rccl_single every torch.empty / zeros (+ _like) of >= 256 KB on the device is logged
+    as `start end bytes shape` — to match the address of a runtime 'Memory access fault' against the buffers that were alive (debug aid, round 3)."""
+    path = os.environ.get("EGOMI_ALLOC_TRACE")
+    name = request.module.__name__.rsplit(".", 1)[-1]
+    if not path or name not in ("test_gpu_train_modes", "test_gpu_rccl_single"):
+        yield
+        return
+    import torch
+    f = open(path, "a")
+    f.write(f"# module {name}\n")
+    orig = {k: getattr(torch, k) for k in ("empty", "zeros", "empty_like", "zeros_like", "full")}
+
+    def wrap(fn, k):
+        def w(*a, **kw):
+            t = fn(*a, **kw)
+            if t.is_cuda and t.numel() * t.element_size() >= (256 << 10):
+                n = t.numel() * t.element_size()
+                f.write(f"{t.data_ptr():#x} {t.data_ptr() + n:#x} {n} {k} {tuple(t.shape)} {t.dtype}\n")
+                f.flush()
+            return t
+        return w
+    for k, fn in orig.items():
+        setattr(torch, k, wrap(fn, k))
+    try:
+        yield
+    finally:
+        for k, fn in orig.items():
+            setattr(torch, k, fn)
+        f.close()

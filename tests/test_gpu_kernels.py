@@ -667,7 +667,10 @@ def test_fused_attention_backward(ops, B, S, H, causal, masked, hd):
 
 @pytest.mark.parametrize("B,S,H,causal,mask,rope", [(2, 692, 3, True, "tail", True), (1, 692, 2, True, None, False), (1, 200, 2, True, "holes", True),
                                                     (2, 64, 1, False, "tail", False), (1, 33, 2, True, None, True), (1, 1, 1, True, None, False),
-                                                    (2, 300, 2, False, "holes", False), (1, 1000, 1, True, "tail", True)])
+                                                    (2, 300, 2, False, "holes", False), (1, 1000, 1, True, "tail", True),
+                                                    # S % 32 == 0 over several tiles: no clamped last tile anywhere (round 3: the dK/dV kernel's LSE / delta
+                                                    # fetch of the last tile ran 128 B past the end of those arrays here; S = 256 was the first such S in the suite)
+                                                    (8, 256, 16, True, "tail", True), (2, 512, 2, False, None, False), (1, 128, 1, True, None, True)])
 def test_fused_attention_backward_second_form_is_bit_identical(ops, B, S, H, causal, mask, rope):
     """attn_bwd_dq2_kernel / attn_bwd_dkdv2_kernel against the first forms: the same arithmetic in the same order -> the same bits in dq, dk,
     dv and delta (interior, diagonal, ragged and padded tiles, dead waves, with and without the inverse-RoPE epilogue)."""
@@ -687,7 +690,12 @@ def test_fused_attention_backward_second_form_is_bit_identical(ops, B, S, H, cau
             km[-1, S // 2] = 0
         km = km.cuda()
     out = torch.zeros(B * S, d, dtype=torch.bfloat16, device="cuda")
-    lse = torch.zeros(B, H, S, dtype=torch.float32, device="cuda")
+    # LSE and delta sit at the very END of allocations of their own (16 MB: a segment of its own in the caching allocator), so that a read past
+    # their last element leaves the mapped segment instead of landing in a neighbouring tensor
+    def at_end(n):
+        buf = torch.zeros((16 << 20) // 4, dtype=torch.float32, device="cuda")
+        return buf[buf.numel() - n:].view(B, H, S), buf
+    lse, _keep0 = at_end(B * H * S)
     ops.attn_fwd(qkv, B, S, H, hd, hd ** -0.5, out, lse, causal=causal, key_mask=km)
     rp = None
     if rope:
@@ -698,7 +706,8 @@ def test_fused_attention_backward_second_form_is_bit_identical(ops, B, S, H, cau
         for form in (1, 2):
             assert L.egomi_attn_set_bwd_form(form) == 0
             dqkv = torch.full((B * S, 3 * d), 3.0, dtype=torch.bfloat16, device="cuda")
-            delta = torch.full((B, H, S), 3.0, dtype=torch.float32, device="cuda")
+            delta, _keep1 = at_end(B * H * S)
+            delta.fill_(3.0)
             ops.attn_bwd(qkv, out, lse, dout, dqkv, delta, B, S, H, hd, hd ** -0.5, causal=causal, key_mask=km, rope=rp)
             torch.cuda.synchronize()
             res[form] = (dqkv, delta)
