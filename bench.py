@@ -326,6 +326,8 @@ def main():
     fps_start = torch.zeros(B, dtype=torch.int32, device=dev)
     N = dims.pb.npoints
 
+    OVERLAP_OPT = os.environ.get("EGOMI_OPT_OVERLAP", "1") != "0"          # A/B switch: 0 = AdamW alone between two steps, on the compute stream
+
     def barrier():
         if world > 1:
             dist.barrier()
@@ -340,7 +342,7 @@ def main():
             loss = model.loss_and_backward(toks, masks, pc, Lp, dims.tok.pad, fps_start=fps_start)                # A3-A15
             if sync is not None:
                 sync.finish()
-            opt.step(grad_scale=sync.grad_scale if sync is not None else 1.0)
+            opt.step(grad_scale=sync.grad_scale if sync is not None else 1.0, overlap=OVERLAP_OPT)   # the update runs under the next step's forward pass
             return loss
         for i in range(warmup):
             step(check=(i == 0))

@@ -60,6 +60,7 @@ class Engine:
         self.reduced_grad = {}         # resident exchange (dp.GradSync(resident=True)): name -> bf16 view of the rank-summed gradient in the
         self.layer_offs = {}           # layer's wire buffer, read by EgoAdamW; layer_offs[l][name] = element offset inside the layer's flat block
         self._direct, self._direct_done = None, set()
+        self.param_events = {}         # EgoAdamW.step(overlap=True): group ("pre" | "embed" | layer index | "post") -> event of its side-stream update
         self.use_fused_attention = True
         self.use_fused_swiglu = os.environ.get("EGOMI_NO_FUSED_SWIGLU", "0") != "1"   # SwiGLU in the gate|up GEMM epilogue where the 256x256
                                                                                       # kernel runs (tests and A/B runs switch it off)
@@ -73,6 +74,28 @@ class Engine:
         self.pb_train_mode = False          # set by TrajPointLLMForCausalLM.train(): point backbone in train() mode
         self.prepared_bn_stale = False
         self.fold_stale = False
+
+    @staticmethod
+    def param_group_of(name):
+        """The point of the forward pass at which a parameter is first read (EgoAdamW.step(overlap=True) updates in this order)."""
+        if name.startswith("model.layers."):
+            return int(name.split(".")[2])
+        if name == "model.embed_tokens.weight":
+            return "embed"
+        if name in ("model.norm.weight", "lm_head.weight"):
+            return "post"
+        return "pre"                                       # projector, point backbone
+
+    def wait_params(self, key):
+        """Forward pass: the compute stream waits for the optimizer's side-stream update of this group, if one is still pending."""
+        ev = self.param_events.pop(key, None)
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
+
+    def wait_param_updates(self):
+        """Everything the optimizer still has in flight (readers outside a forward pass: state_dict, generate, checkpoints)."""
+        for key in list(self.param_events):
+            self.wait_params(key)
 
     def _notify(self, name):
         if self.grad_sync is not None and name in self.trainable and name in self.main_grad:
@@ -139,6 +162,7 @@ class Engine:
 
     def prepare(self):
         """One-time derived weights: BatchNorm fold (fold_batchnorm), resident transposes / stacks of the decoder weights, RoPE tables."""
+        self.wait_param_updates()                           # (derived weights read the parameters: nothing of an overlapped optimizer step may be in flight)
         w, pb, lm = self.w, self.dims.pb, self.dims.lm
         self.fold_batchnorm()
         # frozen decoder weights: keep W^T resident too, so dgrad (dX = dY.W) runs on the tuned
@@ -380,6 +404,7 @@ class Engine:
         Pn = pb.point_token_len
         ctx = {"B": B, "S": S, "ids": input_ids, "layers": []} if save else None
         past = 0
+        self.wait_params("pre")
         # ---- point branch (pointllm.py:112-129): only when S != 1 (prefill / training)
         feats_proj, start_pos, pending_err, cloud_idx, Bc = None, None, None, None, 0
         if point_clouds is not None and S != 1:
@@ -422,6 +447,7 @@ class Engine:
             ctx["start_pos"], ctx["cloud_idx"], ctx["n_clouds"] = start_pos, cloud_idx, Bc
             ctx["has_points"] = feats_proj is not None
         x = ws.get("x_emb", (B, S, d), T) if not save else torch.empty(B, S, d, dtype=T, device=self.device)
+        self.wait_params("embed")
         ops.embed_splice(input_ids, w["model.embed_tokens.weight"], feats_proj, start_pos, Pn, out=x, cloud_idx=cloud_idx)
         x = x.view(M, d)
         key_mask = None
@@ -436,6 +462,7 @@ class Engine:
         fuse_swiglu = self.use_fused_swiglu and T == torch.bfloat16 and self.gu_il and (2 * Fd) % 256 == 0 and ops.gemm_kernel_id(M, 2 * Fd, d) == 2
         for l in range(L):
             p = f"model.layers.{l}."
+            self.wait_params(l)
             if save:
                 lc = {"x_in": x, "rstd1": torch.empty(M, dtype=torch.float32, device=self.device),
                       "rstd2": torch.empty(M, dtype=torch.float32, device=self.device),
@@ -507,6 +534,7 @@ class Engine:
                 lc.update(P=Pm, lse=lse, x_mid=x_mid, h=h, ao=ao, h2=h2, act=act)
                 ctx["layers"].append(lc)
             x = x_out
+        self.wait_params("post")
         rstd_f = torch.empty(M, dtype=torch.float32, device=self.device) if save else None
         hn = torch.empty(M, d, dtype=T, device=self.device)
         ops.rmsnorm(x, w["model.norm.weight"], lm.rms_norm_eps, rstd=rstd_f, out=hn, tail=pend, tail_residual=pend_res)

@@ -16,19 +16,51 @@ class EgoAdamW:
                 master = p.data if p.dtype == torch.float32 else p.data.float()
                 self.state[n] = {"p": p, "master": master, "m": torch.zeros_like(master), "v": torch.zeros_like(master)}
 
-    def step(self, grad_scale=1.0, lr=None):
+    def _update(self, n, st, eng, lr, grad_scale):
+        g = eng.reduced_grad.get(n)                        # resident exchange (dp.GradSync(resident=True)): the rank-summed bf16 gradient, read
+        if g is None:                                      # in place from the layer's wire buffer
+            g = eng.main_grad.get(n)
+        if g is None:
+            return
+        p = st["p"]
+        copy = None if p.dtype == torch.float32 else p.data
+        ops.adamw(st["master"], copy, g, st["m"], st["v"], lr, self.betas[0], self.betas[1], self.eps, self.wd, self.t, grad_scale)
+
+    def step(self, grad_scale=1.0, lr=None, overlap=False):
+        """overlap=True (training loops that go straight on to the next forward pass: bench.py, driver.train): the updates run on a side stream in
+        the order the NEXT forward pass needs the tensors — projector / point backbone, embedding, decoder layers 0..L-1, final norm + lm_head — with
+        one event per group, and the engine's forward waits for a group right before it first reads it (Engine.wait_params).  The pass is HBM-bound
+        (30 B per parameter) and shares the CUs with the MFMA-bound forward products instead of running alone between two steps; values are the
+        same.  Whoever reads parameters or optimizer state outside a forward pass calls engine.wait_param_updates() first (state_dict, generate,
+        checkpoints and this class's own state accessors do)."""
         self.t += 1
         lr = self.lr if lr is None else lr
         eng = self.model.engine
-        for n, st in self.state.items():
-            g = eng.reduced_grad.get(n)                    # resident exchange (dp.GradSync(resident=True)): the rank-summed bf16 gradient, read
-            if g is None:                                  # in place from the layer's wire buffer
-                g = eng.main_grad.get(n)
-            if g is None:
-                continue
-            p = st["p"]
-            copy = None if p.dtype == torch.float32 else p.data
-            ops.adamw(st["master"], copy, g, st["m"], st["v"], lr, self.betas[0], self.betas[1], self.eps, self.wd, self.t, grad_scale)
+        if not (overlap and eng.device.type == "cuda" and not any(nm in eng.trainable for nm in eng.wT)):
+            eng.wait_param_updates()
+            for n, st in self.state.items():
+                self._update(n, st, eng, lr, grad_scale)
+            eng.after_weights_update()
+            return
+        groups = {}
+        for n in self.state:
+            groups.setdefault(eng.param_group_of(n), []).append(n)
+        L = eng.dims.lm.num_hidden_layers
+        order = ["pre", "embed"] + list(range(L)) + ["post"]
+        cur = torch.cuda.current_stream()
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream()
+        self._side.wait_stream(cur)                        # gradients final (and exchanged); every reader of the old weights has been queued
+        with torch.cuda.stream(self._side):
+            for key in order:
+                names = groups.get(key)
+                if not names:
+                    continue
+                for n in names:
+                    self._update(n, self.state[n], eng, lr, grad_scale)
+                ev = torch.cuda.Event()
+                ev.record(self._side)
+                eng.param_events[key] = ev
         eng.after_weights_update()
 
     def zero_grad(self):
@@ -37,19 +69,23 @@ class EgoAdamW:
             st["p"].grad = None
 
     def state_dict(self):
+        self.model.engine.wait_param_updates()
         return {"t": self.t, "state": {n: {k: st[k] for k in ("master", "m", "v")} for n, st in self.state.items()}}
 
     def state_dict_cpu(self):
+        self.model.engine.wait_param_updates()
         return {"t": self.t, "state": {n: {k: st[k].detach().cpu() for k in ("master", "m", "v")} for n, st in self.state.items()}}
 
     def resync_masters(self):
         """After loading a checkpoint: the low-precision model copies follow the fp32 masters again."""
+        self.model.engine.wait_param_updates()
         for st in self.state.values():
             if st["p"].dtype != torch.float32:
                 st["p"].data.copy_(st["master"])
         self.model.engine.after_weights_update()
 
     def load_state_dict(self, sd):
+        self.model.engine.wait_param_updates()
         self.t = sd["t"]
         for n, s in sd["state"].items():
             for k in ("master", "m", "v"):

@@ -249,13 +249,21 @@ class TrajPointLLMForCausalLM(nn.Module):
     def get_model(self):
         return self.model
 
+    def state_dict(self, *a, **k):
+        if getattr(self, "engine", None) is not None:
+            self.engine.wait_param_updates()                # an overlapped optimizer step (EgoAdamW.step(overlap=True)) may still be writing parameters
+        return super().state_dict(*a, **k)
+
     def _apply(self, fn, *a, **k):
+        if getattr(self, "engine", None) is not None:
+            self.engine.wait_param_updates()
         r = super()._apply(fn, *a, **k)
         if getattr(self, "engine", None) is not None:
             self._build_engine()
         return r
 
     def load_state_dict(self, sd, strict=True, **kw):
+        self.engine.wait_param_updates()
         r = super().load_state_dict(sd, strict=strict, **kw)
         self.engine.prepared = False
         self.engine.lm_wT_stale = True          # the padded lm_head transpose follows the loaded values
@@ -434,6 +442,7 @@ class TrajPointLLMForCausalLM(nn.Module):
         the outputs are cut after the step at which every row has finished.  eos_token_id=None: fixed length, never stops."""
         from ..decode import Decoder
         eng = self.engine
+        eng.wait_param_updates()                           # the decoder reads the weights outside the engine's forward pass
         dev = eng.device
         ids = input_ids.to(dev)
         if fps_start is None and point_clouds is not None:

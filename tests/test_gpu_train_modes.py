@@ -152,3 +152,43 @@ def test_unfrozen_stacked_products_over_parameter_views():
     assert l2 < loss_s, (loss_s, l2)
     sd = m.state_dict()
     assert sd["model.layers.1.self_attn.k_proj.weight"].shape == (d, d) and sd["model.layers.1.mlp.up_proj.weight"].is_contiguous()
+
+
+@pytest.mark.parametrize("unfreeze", [False, True])
+def test_overlapped_optimizer_step_equals_the_plain_one(unfreeze):
+    """EgoAdamW.step(overlap=True): the updates run on a side stream in the order the next forward pass reads the tensors, the forward waits per
+    group (Engine.wait_params).  Same losses and the same weights as the plain step over three steps; reading through state_dict() / generate()
+    waits for the updates in flight."""
+    from egoscaler_amd.optim import EgoAdamW
+    dims = _dims()
+    toks, masks, Lp = synth.synth_batch(dims, 4, text_len=8, num_steps=4, max_traj_token=40)
+    pts = torch.stack([synth.synth_cloud(dims, i) for i in range(4)])
+    start = [0, 17, 3, 9]
+    res = {}
+    for overlap in (False, True):
+        m = _model(dims, unfreeze, torch.bfloat16)
+        m.train()
+        opt = EgoAdamW(m, lr=2e-3, weight_decay=0.01)
+        losses = []
+        for _ in range(3):
+            losses.append(float(m.loss_and_backward(toks.cuda(), masks.cuda(), pts.cuda(), Lp, dims.tok.pad, fps_start=start)))
+            opt.step(overlap=overlap)
+        if overlap:
+            assert m.engine.param_events                      # updates of the last step are still registered ...
+        sd = {k: v.detach().clone() for k, v in m.state_dict().items()}       # ... and state_dict() waits for them
+        assert not m.engine.param_events
+        st = opt.state_dict_cpu()
+        res[overlap] = (losses, sd, st)
+        if overlap:                                           # generation right after an overlapped step reads finished weights
+            opt.step(overlap=True)
+            out = m.generate(input_ids=toks[:, :Lp].cuda(), attention_mask=masks[:, :Lp].cuda(), point_clouds=pts.cuda(), max_length=3, do_sample=False,
+                             fps_start=start)
+            assert out.sequences.shape == (4, Lp + 3) and not m.engine.param_events
+    (la, sa, oa), (lb, sb, ob) = res[False], res[True]
+    # the scalar loss and the norm-weight / embedding gradients are fp32 atomic sums (order changes from run to run): first loss to fp32 rounding,
+    # the rest to bf16 rounding
+    assert abs(la[0] - lb[0]) <= 1e-6 * abs(la[0]) and all(abs(x - y) <= 2e-3 * abs(x) for x, y in zip(la, lb)), (la, lb)
+    for k in sa:
+        if sa[k].dtype.is_floating_point:
+            assert float((sa[k].float() - sb[k].float()).abs().max()) <= 2e-2 * float(sa[k].float().abs().max()) + 1e-6, k
+    assert oa["t"] == ob["t"] == 3
