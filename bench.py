@@ -326,7 +326,10 @@ def main():
     fps_start = torch.zeros(B, dtype=torch.int32, device=dev)
     N = dims.pb.npoints
 
-    OVERLAP_OPT = os.environ.get("EGOMI_OPT_OVERLAP", "1") != "0"          # A/B switch: 0 = AdamW alone between two steps, on the compute stream
+    # AdamW under the next step's forward pass (EgoAdamW.step(overlap=True)) where most parameters train: unfrozen 226.8 -> 224.1 ms.  With the frozen LLM
+    # (1.4 ms of AdamW) it measured -0.35 ... +0.5 ms — the update's waves slow the latency-bound point branch it lands on (FPS 0.57 -> 1.18 ms) — so the
+    # headline mode keeps the plain step.  EGOMI_OPT_OVERLAP=0 / 1 forces either (A/B runs)
+    OVERLAP_OPT = os.environ.get("EGOMI_OPT_OVERLAP", "1" if a.mode == "unfrozen" else "0") != "0"
 
     def barrier():
         if world > 1:

@@ -261,7 +261,8 @@ def train(args, model, train_data, val_data=None, device="cuda", log=print, step
             if sync is not None:
                 sync.finish()
             lr_now = linear_warmup_lr(float(args.lr_llm), global_step, total_steps)
-            opt.step(grad_scale=1.0 / (accum * world), lr=lr_now, overlap=True)     # on a side stream, under the next step's forward pass (optim.py)
+            opt.step(grad_scale=1.0 / (accum * world), lr=lr_now, overlap=model.engine.any_layer_trainable)   # --unfreeze_language_model: on a side stream,
+                                                                                                              # under the next step's forward pass (optim.py)
             if step_log is not None:
                 step_log({"epoch": epoch, "step": global_step, "learning_rate": lr_now, "loss": float(loss) if accum == 1 else None})
             global_step += 1
