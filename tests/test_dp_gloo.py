@@ -80,6 +80,71 @@ def test_grad_sync_world2_gloo():
     assert torch.equal(res[0][8], res[1][8])                             # replicas hold identical reduced values
 
 
+def _resident_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        s = GradSync(wire_dtype=torch.bfloat16, wire_min_bytes=1024, resident=True)
+        s.begin_step()
+        n = 1003                                                       # not a multiple of world * 8: the wire buffer is padded (pad stays zero)
+        wire = s.resident_wire("layer0", n, torch.device("cpu"))
+        contrib = lambda r: (torch.arange(n, dtype=torch.float32) * (1.0 + 1e-3 * r) + 0.123)       # noqa: E731
+        wire[:n] = contrib(rank).bfloat16()                            # what the engine's weight-gradient products write: this rank's bf16 gradient
+        s.ready_resident("layer0", wire)
+        s.finish()
+        acc = contrib(0).bfloat16().float()
+        for r in range(1, world):
+            acc += contrib(r).bfloat16().float()
+        ok = bool(torch.equal(wire[:n].float(), acc.bfloat16().float()) and float(wire[n:].abs().max()) == 0 and wire.dtype == torch.bfloat16)
+        same_buffer = s.resident_wire("layer0", n, torch.device("cpu")).data_ptr() == wire.data_ptr()       # persistent per tag
+        too_small = s.resident_wire("tiny", 16, torch.device("cpu")) is None                                  # below wire_min_bytes: packed route
+        off = GradSync(wire_dtype=torch.bfloat16, wire_min_bytes=1024).resident_wire("layer0", n, torch.device("cpu")) is None
+        q.put((rank, ok, same_buffer, too_small, off, dict(s.stats), wire.clone()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_resident_exchange_world2_gloo():
+    """dp.GradSync(resident=True) on two ranks: the bucket IS its bf16 wire buffer — all-to-all, fp32 rank sum, all-gather in place — and afterwards holds the
+    sum over ranks of the bf16 contributions (fp32 accumulation, rounded once), identical on both ranks; the same bits the packed route produces."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_resident_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = sorted((q.get(timeout=90) for _ in range(world)), key=lambda r: r[0])
+    for p in ps:
+        p.join(30)
+        assert p.exitcode == 0
+    for r in res:
+        assert r[1] and r[2] and r[3] and r[4], r[:5]
+        assert r[5]["buckets"] == 1 and r[5]["collective_calls"] == 2 and r[5]["resident_buckets"] == 1
+    assert torch.equal(res[0][6], res[1][6])
+
+
+def test_engine_host_logic_for_stacked_views_and_parameter_groups():
+    """Host-only pieces of the round-3 engine: Engine._side_by_side (the stacked [Wq;Wk;Wv] / [Wgate;Wup] operands and gradient blocks are VIEWS of tensors
+    that lie back to back in one allocation) and Engine.param_group_of (the order in which the next forward pass reads the parameters)."""
+    from egoscaler_amd.engine import Engine
+    block = torch.arange(6 * 4, dtype=torch.float32).view(6, 4)
+    q, k, v = block[0:2], block[2:4], block[4:6]
+    st = Engine._side_by_side([q, k, v])
+    assert st is not None and st.shape == (6, 4) and st.data_ptr() == q.data_ptr() and torch.equal(st, block)
+    st[3, 1] = -1.0
+    assert float(k[1, 1]) == -1.0                                       # a view: writes land in the parameters
+    assert Engine._side_by_side([q, v]) is None                         # a gap between them
+    assert Engine._side_by_side([q, k.clone()]) is None                 # another allocation
+    assert Engine._side_by_side([q, block[2:4, :3]]) is None            # different width / not contiguous
+    flat = torch.zeros(64 + 64)
+    a, b = flat[0:8].view(2, 4), flat[64:72].view(2, 4)                 # padded to 64 elements each, as the layer's gradient block pads them
+    assert Engine._side_by_side([a, b]) is None
+    assert Engine.param_group_of("model.layers.17.mlp.up_proj.weight") == 17 and Engine.param_group_of("model.embed_tokens.weight") == "embed"
+    assert Engine.param_group_of("lm_head.weight") == "post" and Engine.param_group_of("model.norm.weight") == "post"
+    assert Engine.param_group_of("model.point_proj.0.bias") == "pre" and Engine.param_group_of("model.point_backbone.cls_token") == "pre"
+
+
 def test_shard_range_and_single_process():
     assert shard_range(64, 3, 8) == (24, 32)
     with pytest.raises(ValueError):
