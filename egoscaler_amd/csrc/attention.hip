@@ -158,7 +158,7 @@ __device__ __forceinline__ void store_rows_via_lds(char* wbuf, const f32x16 (&ac
     for (int it = 0; it < 8; ++it) {
         const int r = it * 4 + (lane >> 4), ch = lane & 15;
         u32x4 v = *reinterpret_cast<const u32x4*>(wbuf + r * AT_XPITCH + ch * 16);
-        if (rcos && row0 + r < nrows) {
+        if (rcos && row0 + r < nrows && row0 + r >= 0) {
             // inverse rotation of the pair (d, d+64) on the bf16-rounded values, in egomi_rope's own rounding sequence
             // (elementwise.hip rope_vec8_kernel, inverse = 1): lanes 0..7 of a row hold the first halves, 8..15 the second
             const u32x4 w = *reinterpret_cast<const u32x4*>(wbuf + r * AT_XPITCH + (ch ^ 8) * 16);
@@ -175,7 +175,7 @@ __device__ __forceinline__ void store_rows_via_lds(char* wbuf, const f32x16 (&ac
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] = (uint32_t)f2bf(out[2 * j]) | ((uint32_t)f2bf(out[2 * j + 1]) << 16);
         }
-        if (row0 + r < nrows) *reinterpret_cast<u32x4*>(gbase + (long long)(row0 + r) * ld + ch * 8) = v;
+        if (row0 + r < nrows && row0 + r >= 0) *reinterpret_cast<u32x4*>(gbase + (long long)(row0 + r) * ld + ch * 8) = v;
     }
 }
 
@@ -216,7 +216,10 @@ extern "C" int egomi_attn_stamp_reset() { unsigned long long z[16] = {0}; return
 #define STAMP_NOW(var) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory"); __builtin_amdgcn_sched_barrier(0); }
 #define STAMP_START { STAMP_NOW(st_prev) st_t0 = st_prev; }
 #define STAMP(i) { unsigned long long st_n; STAMP_NOW(st_n) st_acc[i] += st_n - st_prev; st_prev = st_n; }
-#define STAMP_FLUSH if (threadIdx.x == 0) { for (int i = 0; i < 8; ++i) atomicAdd(&g_attn_stamp[i], st_acc[i]); atomicAdd(&g_attn_stamp[8], 1ull); }
+#ifndef ATTN_STAMP_WAVE
+#define ATTN_STAMP_WAVE 0
+#endif
+#define STAMP_FLUSH if (threadIdx.x == 64 * ATTN_STAMP_WAVE) { for (int i = 0; i < 8; ++i) atomicAdd(&g_attn_stamp[i], st_acc[i]); atomicAdd(&g_attn_stamp[8], 1ull); }
 #else
 #define STAMP_DECL
 #define STAMP_START
@@ -727,6 +730,269 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(AttnArgs a) {
     }
     if (qi < a.S && half == 0 && a.lse)                                // natural-log LSE of the SCALED scores
         a.lse[((long long)b * a.H + h) * a.S + qi] = (m_run == -INFINITY) ? INFINITY : m_run * 0.6931471805599453f + logf(l_run);
+}
+
+
+// =================================================================================================
+// forward, third form (round 4; the default at head_dim 128 — EGOMI_ATTN_FWD=2 / =1 select the forms above for A/B runs).
+// The second form's counters said: VALU 44 % / MFMA pipe 19 % of SIMD time, 37 % of a block's life in prologue + epilogue, two barriers
+// per 64-key tile, a wave's QK -> softmax -> PV phases strictly one after the other.  What changes:
+//   * software pipeline inside the wave: the scores of tile t+1 (8 MFMAs) are issued under the exponentials of tile t, the mask + row max
+//     of tile t+1 under the P.V MFMAs of tile t — each phase has work for both pipes of the SIMD;
+//   * 32-key tiles in a 4-stage LDS ring (4 x (8 KB K + 8 KB V) = the same 64 KB): tile t+3 is requested at the top of tile t, ONE
+//     barrier per tile (the wave's own `vmcnt` for tile t+1 in front of it), nothing waits for a DMA issued less than two tiles ago;
+//   * lazy running max (cdna_hip_programming.md T13): the 64 accumulator multiplies and the alpha exponential run only when some query
+//     of the wave meets a score more than 2^F3_THR above its reference maximum; l and O stay relative to that reference, LSE is exact
+//     (m ln2 + ln l).  P <= 2^F3_THR in bf16: same relative precision, results differ from the earlier forms in the last bits;
+//   * query blocks aligned to the END of the sequence (rounded up to 32): the ragged block is the FIRST one (shortest causal range)
+//     instead of the last (S = 692: 36 instead of 41 64-key tile-steps per (b, h) pair, and no block runs 11 tiles with half its waves dead);
+//   * the row sum is kept per lane (each half-wave sums its own keys) and combined once at the end.
+// =================================================================================================
+#define F3_KT 32
+#define F3_NST 4
+#define F3_TB (F3_KT * 256)                                            // bytes of one 32-key K or V tile (head_dim 128)
+#define F3_STAGE (2 * F3_TB)
+#define F3_THR 6.0f
+
+// one pipelined step: exponentials of tile t (scores in x, reference max m_run) beside the scores of tile t+1 (-> xn), then P.V of tile t
+// beside the mask + row max of tile t+1; the reference max moves only in the rare branch at the end.  HAS_NEXT = false: the wave's last tile.
+template <bool MASKED_NEXT, bool HAS_NEXT>
+__device__ __forceinline__ void f3_step(const char* sKn, const char* sV, const bf16x8 (&qf)[8], f32x16& x, f32x16 (&o)[4],
+                                        float& m_run, float& l_run, const float sc2, const uint32_t vis_next, const int lane, const int half) {
+    const float nm = m_run == -INFINITY ? 0.f : -m_run;
+    f32x16 xn;
+    bf16x8 kf[8];
+    if (HAS_NEXT) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) xn[r] = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) kf[i] = lds_row8(sKn, lane & 31, 2 * i + half);
+    }
+    bf16x8 vf[8];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) vf[dt] = lds_tr8(sV, 0, 32 * dt, lane);
+    float lsum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        if (HAS_NEXT) xn = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[i], qf[i], xn, 0, 0, 0);
+#pragma unroll
+        for (int r = 2 * i; r < 2 * i + 2; ++r) {
+            const float p = fast_exp2(fmaf(x[r], sc2, nm));            // exp2(-inf) = 0 for masked keys
+            x[r] = p;
+            lsum += p;
+        }
+    }
+    l_run += lsum;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) vf[4 + dt] = lds_tr8(sV, 16, 32 * dt, lane);
+    float pv8[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) pv8[j] = x[j];
+    const bf16x8 pb0 = pack8(pv8);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) pv8[j] = x[8 + j];
+    const bf16x8 pb1 = pack8(pv8);
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[dt], pb0, o[dt], 0, 0, 0);
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[4 + dt], pb1, o[dt], 0, 0, 0);
+    if (HAS_NEXT) {
+        if (MASKED_NEXT) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) xn[r] = (vis_next >> rowmap(r, 0)) & 1u ? xn[r] : -INFINITY;
+        }
+        float mloc = fmaxf(xn[0], xn[1]);
+#pragma unroll
+        for (int r = 2; r < 16; r += 2) mloc = fmaxf(mloc, fmaxf(xn[r], xn[r + 1]));
+        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64)) * sc2;              // sc2 > 0: max commutes with the scale
+        if (__any(mloc > m_run + F3_THR)) {                              // rare after the first tiles (always at the first one: m_run = -inf)
+            const float m_new = fmaxf(m_run, mloc);
+            const float alpha = m_run == -INFINITY ? 0.f : fast_exp2(m_run - m_new);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+            l_run *= alpha;
+            m_run = m_new;
+        }
+        x = xn;
+    }
+}
+
+// Block order of the third form.  group == 0: rank-major as attn_block_map.  group = G > 0 (needs H*B % 8 == 0): blocks that share an XCD
+// (equal blockIdx % 8) walk that XCD's (b, h) pairs in GROUPS of G consecutive ranks — the G blocks of a pair are adjacent in the dispatch
+// order, so they run at the same time on one XCD and the K/V tiles the first of them brings into that XCD's L2 serve the others; groups
+// still go longest ranks first.  Grid = 8 * (pairs/8) * G * ceil(nblk/G); ranks >= nblk (nblk % G != 0) leave at once.
+__device__ __forceinline__ bool attn_block_map3(const AttnArgs& a, const int nblk, const int group, int& rank, int& h, int& b) {
+    if (group <= 0) { attn_block_map(a, rank, h, b); return true; }
+    const int pairs = a.H * a.B, ppx = pairs >> 3;
+    const int x = blockIdx.x & 7, k = blockIdx.x >> 3;
+    const int per_phase = ppx * group;
+    const int phase = k / per_phase, j = k - phase * per_phase;
+    const int pl = j / group, rr = j - pl * group;
+    const int pair = pl * 8 + x;
+    rank = __builtin_amdgcn_readfirstlane(phase * group + rr);
+    b = pair / a.H; h = pair - b * a.H;
+    b = __builtin_amdgcn_readfirstlane(b); h = __builtin_amdgcn_readfirstlane(h);
+    return rank < nblk;
+}
+
+__global__ __launch_bounds__(256, 2) void attn_fwd3_kernel(AttnArgs a, const int group) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];       // [4 stages][K 8 KB | V 8 KB] + key mask bytes
+    char* sMask = smem + F3_NST * F3_STAGE;
+    const int lane = threadIdx.x & 63, half = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int rank, h, b;
+    const int S32 = (a.S + 31) & ~31;
+    if (!attn_block_map3(a, (S32 + 127) / 128, group, rank, h, b)) return;
+    const int q0 = S32 - 128 * (rank + 1);                             // may be negative for the last rank (the shortest block)
+    const long long row_base = (long long)b * a.S;
+    const bf16_t* Q = a.q + row_base * a.ld_qkv + h * AT_HD;
+    const bf16_t* K = a.k + row_base * a.ld_qkv + h * AT_HD;
+    const bf16_t* V = a.v + row_base * a.ld_qkv + h * AT_HD;
+    const int wave_q0 = q0 + wave * 32;                                // a multiple of 32
+    const int qi = wave_q0 + (lane & 31);
+    const int qr = qi < 0 ? 0 : (qi < a.S ? qi : a.S - 1);
+    const int last = q0 + 127 < a.S - 1 ? q0 + 127 : a.S - 1;         // >= 0 for every launched block
+    const int nkt = (a.S + F3_KT - 1) / F3_KT;
+    const int ntiles = a.causal ? last / F3_KT + 1 : nkt;
+    // per-lane DMA source offsets (bytes from K resp. V, < 2^32) of this wave's two 1-KiB pieces of tile 0; advanced by 32 rows per request
+    uint32_t koff[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int rl = (wave * 2 + j) * 4 + (lane >> 4);
+        const int ch = (lane & 15) ^ (((rl & 3) << 2) | ((rl >> 2) & 3));
+        const int r = rl < a.S ? rl : a.S - 1;
+        koff[j] = (uint32_t)((long long)r * a.ld_qkv + ch * 8) * 2u;
+    }
+    const uint32_t tile_stride = (uint32_t)(F3_KT * a.ld_qkv * 2);
+    const uint32_t lds0 = (uint32_t)(uintptr_t)((lds_void_t*)smem) + wave * 2 * 1024;
+    int next_req = 0;                                                  // tiles are requested in order 0, 1, 2, ...
+    auto request = [&]() {                                             // K and V rows of tile next_req -> stage next_req % 4
+        const uint32_t base = __builtin_amdgcn_readfirstlane(lds0 + (next_req & (F3_NST - 1)) * F3_STAGE);
+        if ((next_req + 1) * F3_KT <= a.S) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) dma16_asm(K, koff[j], base + j * 1024);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) dma16_asm(V, koff[j], base + F3_TB + j * 1024);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) koff[j] += tile_stride;
+        } else {                                                       // the sequence's ragged last tile: rows clamped to S - 1
+            uint32_t off[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int rl = (wave * 2 + j) * 4 + (lane >> 4);
+                const int ch = (lane & 15) ^ (((rl & 3) << 2) | ((rl >> 2) & 3));
+                int r = next_req * F3_KT + rl;
+                r = r < a.S ? r : a.S - 1;
+                off[j] = (uint32_t)((long long)r * a.ld_qkv + ch * 8) * 2u;
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) dma16_asm(K, off[j], base + j * 1024);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) dma16_asm(V, off[j], base + F3_TB + j * 1024);
+        }
+        ++next_req;
+    };
+    STAMP_DECL
+    STAMP_START
+    request();                                                         // tile 0
+    if (ntiles > 1) request();                                         // tile 1
+    STAMP(0)
+    bf16x8 qf[8];
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(Q + (long long)qr * a.ld_qkv + 16 * ks + 8 * half);
+    uint8_t mv[AT_MASK_IT];
+    mask_fetch(a, row_base, ntiles * F3_KT, mv);
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) asm volatile("" :: "v"(qf[ks]));            // consumed before the loop: see attn_fwd_kernel (the compiler's wait also lands tiles 0, 1)
+    STAMP(1)
+    mask_commit(a, row_base, ntiles * F3_KT, mv, sMask);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (ntiles > 2) request();                                         // tile 2 stays in flight across the barrier
+
+    f32x16 o[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+    const float sc2 = a.scale * 1.4426950408889634f;
+
+    // tile classes of this wave: [0, n_int) fully visible, [n_int, n_live) masked (diagonal, ragged, padded), [n_live, ntiles) not its own
+    const int wl = wave_q0 + 31 < a.S - 1 ? wave_q0 + 31 : a.S - 1;   // the wave's last live query (< 0: none)
+    const int wf = wave_q0 < 0 ? 0 : wave_q0;
+    int n_live = wl < 0 ? 0 : (a.causal ? wl / F3_KT + 1 : ntiles);
+    n_live = n_live < ntiles ? n_live : ntiles;
+    int n_int = a.causal ? (wf >= F3_KT - 1 ? (wf - (F3_KT - 1)) / F3_KT + 1 : 0) : ntiles;
+    n_int = n_int < n_live ? n_int : n_live;
+    if (a.S % F3_KT && n_int == nkt) n_int = nkt - 1;                  // the ragged last tile has keys >= S
+
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                                      // tiles 0 and 1 and the mask bytes are in LDS for every wave
+    STAMP(2)
+    auto top = [&](int t) {                                            // tile t+1 landed for everybody, stage (t+3) % 4 free: request tile t+3
+        if (t + 2 < ntiles) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (t + 3 < ntiles) request();
+    };
+    auto kbits = [&](int t) -> uint32_t { return (uint32_t)__ballot(sMask[t * F3_KT + (lane & 31)] != 0); };
+    f32x16 x;
+    if (n_live > 0) {                                                  // scores and reference max of tile 0
+#pragma unroll
+        for (int r = 0; r < 16; ++r) x[r] = 0.f;
+        bf16x8 kf[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) kf[i] = lds_row8(smem, lane & 31, 2 * i + half);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) x = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[i], qf[i], x, 0, 0, 0);
+        const uint32_t v0 = visible_bits(kbits(0), half, 0, qi, a.causal);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) x[r] = (v0 >> rowmap(r, 0)) & 1u ? x[r] : -INFINITY;
+        float mloc = fmaxf(x[0], x[1]);
+#pragma unroll
+        for (int r = 2; r < 16; r += 2) mloc = fmaxf(mloc, fmaxf(x[r], x[r + 1]));
+        m_run = fmaxf(mloc, __shfl_xor(mloc, 32, 64)) * sc2;
+    }
+    STAMP(3)
+    int t = 0;
+    bool carried = false;
+    uint32_t km = 0u;
+    for (; t < n_int - 1; ++t) {                                       // tile t+1 fully visible: no mask work at all
+        top(t);
+        STAMP(4)
+        km = kbits(t + 1);
+        if (km != 0xFFFFFFFFu) { carried = true; break; }              // a padded key in tile t+1: continue on the masked path
+        f3_step<false, true>(smem + ((t + 1) & 3) * F3_STAGE, smem + (t & 3) * F3_STAGE + F3_TB, qf, x, o, m_run, l_run, sc2, 0u, lane, half);
+        STAMP(5)
+    }
+    for (; t < n_live - 1; ++t) {
+        if (!carried) { top(t); STAMP(4) km = kbits(t + 1); }
+        carried = false;
+        const uint32_t vn = visible_bits(km, half, (t + 1) * F3_KT, qi, a.causal);
+        f3_step<true, true>(smem + ((t + 1) & 3) * F3_STAGE, smem + (t & 3) * F3_STAGE + F3_TB, qf, x, o, m_run, l_run, sc2, vn, lane, half);
+        STAMP(5)
+    }
+    if (n_live > 0) {                                                  // t == n_live - 1: the wave's last tile
+        top(t);
+        STAMP(4)
+        f3_step<false, false>(smem, smem + (t & 3) * F3_STAGE + F3_TB, qf, x, o, m_run, l_run, sc2, 0u, lane, half);
+        STAMP(5)
+        ++t;
+    }
+    for (; t < ntiles; ++t) top(t);                                    // tiles of the block's later waves: DMA share and barriers
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                                      // nobody reads a stage any more: the ring becomes the epilogue's strips
+    STAMP(6)
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+    store_rows_via_lds(smem + wave * AT_XBYTES, o, inv, a.o + row_base * a.ld_o + h * AT_HD, a.ld_o, wave_q0, a.S, lane);
+    if (qi >= 0 && qi < a.S && half == 0 && a.lse)                     // natural-log LSE of the SCALED scores
+        a.lse[((long long)b * a.H + h) * a.S + qi] = (m_run == -INFINITY) ? INFINITY : m_run * 0.6931471805599453f + logf(l_tot);
+    STAMP(7)
+    STAMP_FLUSH
 }
 
 
@@ -1441,12 +1707,23 @@ static bool occ_dq2() { return attn_occ() & 1; }
 
 static int g_attn_fwd_form = -1;
 static int attn_fwd_form() {
-    if (g_attn_fwd_form < 0) { const char* e = getenv("EGOMI_ATTN_FWD"); g_attn_fwd_form = e ? atoi(e) : 2; }
+    if (g_attn_fwd_form < 0) { const char* e = getenv("EGOMI_ATTN_FWD"); g_attn_fwd_form = e ? atoi(e) : 3; }
     return g_attn_fwd_form;
 }
 extern "C" int egomi_attn_set_fwd_form(int form) {
-    if (form != 1 && form != 2) return EGOMI_E_BADARG;
+    if (form < 1 || form > 3) return EGOMI_E_BADARG;
     g_attn_fwd_form = form;
+    return EGOMI_OK;
+}
+// A/B switch for the third form's block order (attn_block_map3): EGOMI_ATTN_GROUP / egomi_attn_set_fwd_group
+static int g_attn_fwd_group = -1;
+static int attn_fwd_group() {
+    if (g_attn_fwd_group < 0) { const char* e = getenv("EGOMI_ATTN_GROUP"); g_attn_fwd_group = e ? atoi(e) : 0; }
+    return g_attn_fwd_group;
+}
+extern "C" int egomi_attn_set_fwd_group(int group) {
+    if (group < 0 || group > 64) return EGOMI_E_BADARG;
+    g_attn_fwd_group = group;
     return EGOMI_OK;
 }
 static int g_attn_bwd_form = -1;
@@ -1490,7 +1767,18 @@ extern "C" int egomi_attn_fwd(const egomi_attn_desc* d, egomi_stream_t stream) {
     const dim3 grid((unsigned)(((d->S + 127) / 128) * d->H * d->B));
     const size_t lds = 2 * 2 * 64 * 2 * (size_t)d->head_dim + (size_t)((d->S + 63) / 64) * 64;
     int form = attn_fwd_form();                                        // EGOMI_ATTN_FWD=1 / egomi_attn_set_fwd_form(1): the first form (A/B runs, equality tests)
-    if ((long long)d->S * d->ld_qkv * 2 >= (1ll << 32)) form = 1;      // the second form addresses K/V rows with 32-bit byte offsets
+    if ((long long)d->S * d->ld_qkv * 2 >= (1ll << 32)) form = 1;      // the second and third forms address K/V rows with 32-bit byte offsets
+    if (d->head_dim == 128 && form == 3) {
+        const int s32 = (d->S + 31) & ~31, nblk = (s32 + 127) / 128;
+        int group = (d->H * d->B) % 8 == 0 ? attn_fwd_group() : 0;
+        if (group > nblk) group = nblk;
+        const int nb = group > 0 ? ((nblk + group - 1) / group) * group : nblk;
+        const dim3 grid3((unsigned)(nb * d->H * d->B));                    // query blocks aligned to the end of the sequence
+        const size_t lds3 = (size_t)F3_NST * F3_STAGE + (size_t)s32;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
+        EGOMI_LAUNCH(attn_fwd3_kernel, grid3, dim3(256), lds3, (hipStream_t)stream, a, group);
+        return egomi_launch_status();
+    }
     if (d->head_dim == 128) {
         if (form == 1) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

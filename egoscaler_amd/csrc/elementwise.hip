@@ -200,17 +200,20 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(T* dy, const T* x, con
     }
 }
 
-// dw[c] += sum_r dy[r,c] * (x[r,c] * rstd[r]) as its own pass: 64 columns per block (8 lanes x 8 columns, 32 rows in flight),
-// rows split over gridDim.y, one atomic per column and block.  The in-kernel form (partials in registers, 1024 blocks x cols
-// atomics onto cols addresses) took 264 us at 5536 x 4096; this pass re-reads dy and x (L2/Infinity-Cache warm) in ~20 us.
+// dw[c] += sum_r dy[r,c] * (x[r,c] * rstd[r]) as its own pass, DETERMINISTIC (round 4): ONE block owns a strip of 32
+// columns over all the rows (4 lanes x 8 columns, 256 rows in flight per iteration), the 256 row-lane partials meet in LDS and are
+// summed in a fixed order, and the owner adds the result to dw with a plain read-modify-write.  No atomics: the same bits every run.
+// (Round 1's form split the rows over gridDim.y and met in dw with fp32 atomics: ~20 us at 5536 x 4096, order-dependent last bits.)
 template <typename T>
-__global__ __launch_bounds__(256) void rmsnorm_dw_kernel(const T* dy, const T* x, const float* rstd, float* dw, int rows, int cols) {
-    __shared__ float red[32][65];
-    const int cl = threadIdx.x & 7, rl = threadIdx.x >> 3;
-    const int c = blockIdx.x * 64 + cl * 8;
+__global__ __launch_bounds__(1024) void rmsnorm_dw_kernel(const T* dy, const T* x, const float* rstd, float* dw, int rows, int cols) {
+    __shared__ float red[256][33];
+    __shared__ float red2[32][33];
+    const int cl = threadIdx.x & 3, rl = threadIdx.x >> 2;
+    const int c = blockIdx.x * 32 + cl * 8;
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (c < cols) {
-        for (long long r = (long long)blockIdx.y * 32 + rl; r < rows; r += 32ll * gridDim.y) {
+#pragma unroll 2
+        for (long long r = rl; r < rows; r += 256) {
             float g[8], xv[8];
             load8<T>(dy + r * cols + c, g);
             load8<T>(x + r * cols + c, xv);
@@ -222,12 +225,20 @@ __global__ __launch_bounds__(256) void rmsnorm_dw_kernel(const T* dy, const T* x
 #pragma unroll
     for (int j = 0; j < 8; ++j) red[rl][cl * 8 + j] = acc[j];
     __syncthreads();
-    if (threadIdx.x < 64) {
+    {
+        const int cc = threadIdx.x & 31, g = threadIdx.x >> 5;
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s += red[g * 8 + k][cc];
+        red2[g][cc] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < 32) {
         float s = 0.f;
 #pragma unroll 8
-        for (int r = 0; r < 32; ++r) s += red[r][threadIdx.x];
-        const int cc = blockIdx.x * 64 + threadIdx.x;
-        if (cc < cols) atomicAdd(dw + cc, s);
+        for (int g = 0; g < 32; ++g) s += red2[g][threadIdx.x];
+        const int cc = blockIdx.x * 32 + threadIdx.x;
+        if (cc < cols) dw[cc] += s;
     }
 }
 
@@ -250,8 +261,7 @@ static int rmsnorm_bwd_impl(void* dy, const void* x, const void* w, const float*
     // one row per block keeps every CU's memory pipe full; the weight gradient, when wanted, is its own pass (above).  With a
     // tail the row kernel runs FIRST: it is the one that materialises dy's last rows, which the weight-gradient pass reads.
     auto dw_pass = [&]() {
-        const int rseg = rows >= 2048 ? 8 : (rows >= 256 ? 2 : 1);
-        EGOMI_DISPATCH_DTYPE(dtype, EGOMI_LAUNCH(rmsnorm_dw_kernel<T>, dim3((cols + 63) / 64, rseg), dim3(256), 0, (hipStream_t)stream,
+        EGOMI_DISPATCH_DTYPE(dtype, EGOMI_LAUNCH(rmsnorm_dw_kernel<T>, dim3((cols + 31) / 32), dim3(1024), 0, (hipStream_t)stream,
                                                        (const T*)dy, (const T*)x, rstd, dw, rows, cols));
         return 0;
     };
@@ -733,26 +743,73 @@ __global__ __launch_bounds__(256) void embed_splice_fwd_kernel(const int64_t* id
     }
 }
 
-// dW[ids] += dout (fp32 atomics, rows outside the point span); dfeats = dout rows inside the span
+// dW[ids] += dout (rows outside the point span); dfeats = dout rows inside the span.  DETERMINISTIC (round 4): a token id that occurs in
+// several rows (pad, <tsep>, repeated bins) used to meet in dW with fp32 atomics.  Now the block of the FIRST row that carries an id OWNS
+// it: it walks the later rows in increasing order, sums the rows with the same id in registers and adds the result to dW with a plain
+// read-modify-write; blocks of later occurrences find an earlier one and leave.  The id list (B*S int64, L2-resident) is scanned 256 rows
+// at a time; blockIdx.y splits the d columns into pieces of 1024 so that an id with many rows is summed by several blocks.
+__device__ __forceinline__ bool esb_in_span(const int32_t* start_pos, long long row, int S, int P) {
+    if (!start_pos) return false;
+    const int b = (int)(row / S), s = (int)(row % S);
+    const int sp = start_pos[b];
+    return sp >= 0 && s > sp && s <= sp + P;
+}
 template <typename T>
 __global__ __launch_bounds__(256) void embed_splice_bwd_kernel(const T* dout, const int64_t* ids, const int32_t* start_pos, const int32_t* cloud_idx,
-                                                               int S, int d, int P, int V, float* dW, T* dfeats) {
+                                                               int S, int d, int P, int V, long long n_rows, float* dW, T* dfeats) {
+    __shared__ unsigned long long hit[4];
     const long long row = blockIdx.x;
     const int b = (int)(row / S), s = (int)(row % S);
     const int sp = start_pos ? start_pos[b] : -1;
     const bool in_span = sp >= 0 && s > sp && s <= sp + P;
     if (in_span) {
-        if (!dfeats) return;
+        if (!dfeats || blockIdx.y) return;
         T* dst = dfeats + ((long long)(cloud_idx ? cloud_idx[b] : b) * P + (s - sp - 1)) * d;
         for (int c = threadIdx.x * 8; c < d; c += 256 * 8) {
             float v[8];
             load8<T>(dout + row * d + c, v);
             store8<T>(dst + c, v);
         }
-    } else if (dW) {
-        const long long t = ids[row];
-        if (t < 0 || t >= V) return;
-        for (int c = threadIdx.x; c < d; c += 256) atomicAdd(dW + t * d + c, Cvt<T>::ld(dout + row * d + c));
+        return;
+    }
+    if (!dW) return;
+    const long long t = ids[row];
+    if (t < 0 || t >= V) return;
+    // an earlier row outside the span with the same id?  then that row's block owns the sum
+    int earlier = 0;
+    for (long long r = threadIdx.x; r < row; r += 256) earlier |= (ids[r] == t && !esb_in_span(start_pos, r, S, P));
+    if (__syncthreads_or(earlier)) return;
+    const int c0 = blockIdx.y * 1024 + threadIdx.x * 4;                 // this thread's 4 columns of the piece
+    const bool live = c0 < d;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    auto add_row = [&](long long r) {
+        if (live) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] += Cvt<T>::ld(dout + r * d + c0 + j);
+        }
+    };
+    add_row(row);
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (long long base = row + 1; base < n_rows; base += 256) {
+        const long long r = base + threadIdx.x;
+        const bool m = r < n_rows && ids[r] == t && !esb_in_span(start_pos, r, S, P);
+        const unsigned long long bal = __ballot(m);
+        __syncthreads();                                                // the previous chunk's masks have been read by everybody
+        if (lane == 0) hit[wv] = bal;
+        __syncthreads();
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            unsigned long long mk = hit[w];
+            while (mk) {                                                // increasing row order: the same sum every run
+                const int j = __builtin_ctzll(mk);
+                mk &= mk - 1;
+                add_row(base + 64 * w + j);
+            }
+        }
+    }
+    if (live) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dW[t * d + c0 + j] += acc[j];
     }
 }
 
@@ -769,15 +826,16 @@ extern "C" int egomi_embed_splice_bwd(const void* dout, const int64_t* ids, cons
                                       int P, int V, float* dW, void* dfeats, int dtype, egomi_stream_t stream) {
     if (!dout || !ids) return EGOMI_E_BADARG;
     if (B <= 0 || S <= 0 || d <= 0 || d % 8 || V <= 0) return EGOMI_E_SHAPE;
-    EGOMI_DISPATCH_DTYPE(dtype, EGOMI_LAUNCH(embed_splice_bwd_kernel<T>, dim3(B * S), dim3(256), 0, (hipStream_t)stream,
-                                                   (const T*)dout, ids, start_pos, cloud_idx, S, d, P, V, dW, (T*)dfeats));
+    EGOMI_DISPATCH_DTYPE(dtype, EGOMI_LAUNCH(embed_splice_bwd_kernel<T>, dim3(B * S, dW ? (d + 1023) / 1024 : 1), dim3(256), 0, (hipStream_t)stream,
+                                                   (const T*)dout, ids, start_pos, cloud_idx, S, d, P, V, (long long)B * S, dW, (T*)dfeats));
     return egomi_launch_status();
 }
 
 // ------------------------------------------------------------------------------------------------
 // A12  cross-entropy over the trajectory span.  reference: train.py:174-181
 // F.cross_entropy(logits, targets, ignore_index=pad): mean over non-ignored rows.
-// ce_count counts them; ce_fwd_bwd adds -log p[target] into loss_sum (fp32 atomics) and writes
+// ce_count counts them; ce_fwd_bwd writes -log p[target] of every row into row_loss (0 for ignored rows), a one-block pass adds them to
+// loss_sum in a fixed order (round 4: the per-row fp32 atomics made the loss differ in its last bits from run to run) and
 // dlogits = (softmax - onehot) * grad_scale / count  (zero rows for ignored targets).
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void ce_count_kernel(const int64_t* tg, long long n, int64_t ignore, int32_t* count) {
@@ -790,13 +848,14 @@ __global__ __launch_bounds__(256) void ce_count_kernel(const int64_t* tg, long l
 
 template <typename T>
 __global__ __launch_bounds__(1024) void ce_fwd_bwd_kernel(const T* logits, long long ld, const int64_t* tg, int V, int64_t ignore,
-                                                          const int32_t* count, float* loss_sum, T* dlogits, long long ldd, float grad_scale) {
+                                                          const int32_t* count, float* row_loss, T* dlogits, long long ldd, float grad_scale) {
     __shared__ float red[16];
     const long long row = blockIdx.x;
     const T* lr = logits + row * ld;
     const int64_t t = tg[row];
     const bool ign = (t == ignore) || t < 0 || t >= V;
     if (ign) {
+        if (threadIdx.x == 0) row_loss[row] = 0.f;
         if (dlogits) for (int c = threadIdx.x; c < V; c += 1024) Cvt<T>::st(dlogits + row * ldd + c, 0.f);
         return;
     }
@@ -810,7 +869,7 @@ __global__ __launch_bounds__(1024) void ce_fwd_bwd_kernel(const T* logits, long 
     for (int c = threadIdx.x; c < V; c += 1024) s += __expf(Cvt<T>::ld(lr + c) - mx);
     s = block_sum(s, red);
     const float lse = mx + __logf(s);
-    if (threadIdx.x == 0) atomicAdd(loss_sum, lse - tl);
+    if (threadIdx.x == 0) row_loss[row] = lse - tl;
     if (dlogits) {
         const float sc = grad_scale / (float)(*count);
         for (int c = threadIdx.x; c < V; c += 1024) {
@@ -821,6 +880,15 @@ __global__ __launch_bounds__(1024) void ce_fwd_bwd_kernel(const T* logits, long 
     }
 }
 
+// loss_sum += sum_i v[i]: one block, strided partials, fixed tree
+__global__ __launch_bounds__(1024) void ordered_sum_kernel(const float* v, int n, float* out) {
+    __shared__ float red[16];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 1024) s += v[i];
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) *out += s;
+}
+
 extern "C" int egomi_ce_count(const int64_t* targets, int64_t n, int64_t ignore, int32_t* count, egomi_stream_t stream) {
     if (!targets || !count) return EGOMI_E_BADARG;
     if (n <= 0) return EGOMI_E_SHAPE;
@@ -829,11 +897,12 @@ extern "C" int egomi_ce_count(const int64_t* targets, int64_t n, int64_t ignore,
 }
 
 extern "C" int egomi_ce_fwd_bwd(const void* logits, int64_t ld, const int64_t* targets, int R, int V, int64_t ignore, const int32_t* count,
-                                float* loss_sum, void* dlogits, int64_t ldd, float grad_scale, int dtype, egomi_stream_t stream) {
-    if (!logits || !targets || !count || !loss_sum) return EGOMI_E_BADARG;
+                                float* loss_sum, float* row_loss, void* dlogits, int64_t ldd, float grad_scale, int dtype, egomi_stream_t stream) {
+    if (!logits || !targets || !count || !loss_sum || !row_loss) return EGOMI_E_BADARG;
     if (R <= 0 || V <= 0 || ld < V || (dlogits && ldd < V)) return EGOMI_E_SHAPE;
     EGOMI_DISPATCH_DTYPE(dtype, EGOMI_LAUNCH(ce_fwd_bwd_kernel<T>, dim3(R), dim3(1024), 0, (hipStream_t)stream,
-                                                   (const T*)logits, ld, targets, V, ignore, count, loss_sum, (T*)dlogits, ldd, grad_scale));
+                                                   (const T*)logits, ld, targets, V, ignore, count, row_loss, (T*)dlogits, ldd, grad_scale));
+    EGOMI_LAUNCH(ordered_sum_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, (const float*)row_loss, R, loss_sum);
     return egomi_launch_status();
 }
 
@@ -1127,23 +1196,31 @@ extern "C" int egomi_linear_smallk(const void* x, int x_dtype, const void* w, co
     return egomi_launch_status();
 }
 
-// column sums: out[c] (+)= sum_r x[r, c]   (bias gradients of the projector, pointllm.py:67-81 backward)
+// column sums: out[c] += sum_r x[r, c]   (bias gradients of the projector, pointllm.py:67-81 backward).  DETERMINISTIC (round 4): one block
+// owns 32 columns over all rows (32 row-lanes), the partials meet in LDS in a fixed order; the row blocks of the earlier form met in `out`
+// with fp32 atomics.
 template <typename T>
-__global__ __launch_bounds__(256) void colsum_kernel(const T* x, long long R, int C, long long ld, float* out, int rows_per_block) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
-    const long long r0 = (long long)blockIdx.y * rows_per_block;
-    long long r1 = r0 + rows_per_block;
-    r1 = r1 < R ? r1 : R;
+__global__ __launch_bounds__(1024) void colsum_kernel(const T* x, long long R, int C, long long ld, float* out) {
+    __shared__ float red[32][33];
+    const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
     float acc = 0.f;
-    for (long long r = r0; r < r1; ++r) acc += Cvt<T>::ld(x + r * ld + c);
-    atomicAdd(out + c, acc);
+    if (c < C) {
+#pragma unroll 4
+        for (long long r = rl; r < R; r += 32) acc += Cvt<T>::ld(x + r * ld + c);
+    }
+    red[rl][cl] = acc;
+    __syncthreads();
+    if (threadIdx.x < 32 && c < C) {
+        float s = 0.f;
+#pragma unroll 8
+        for (int g = 0; g < 32; ++g) s += red[g][threadIdx.x];
+        out[c] += s;
+    }
 }
 extern "C" int egomi_colsum(const void* x, int64_t R, int C, int64_t ld, float* out, int dtype, egomi_stream_t stream) {
     if (!x || !out) return EGOMI_E_BADARG;
     if (R <= 0 || C <= 0 || ld < C) return EGOMI_E_SHAPE;
-    const int rpb = 128;
-    dim3 grid((C + 255) / 256, (unsigned)((R + rpb - 1) / rpb));
-    EGOMI_DISPATCH_DTYPE(dtype, EGOMI_LAUNCH(colsum_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, (const T*)x, (long long)R, C, (long long)ld, out, rpb));
+    EGOMI_DISPATCH_DTYPE(dtype, EGOMI_LAUNCH(colsum_kernel<T>, dim3((C + 31) / 32), dim3(1024), 0, (hipStream_t)stream, (const T*)x, (long long)R, C, (long long)ld, out));
     return egomi_launch_status();
 }

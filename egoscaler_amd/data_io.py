@@ -126,9 +126,10 @@ class FileTrajData:
     over files.  `encode(text) -> list[int]` is the caller's tokenizer (HF tokenizer in the reference);
     `norm` is the target normalisation (traj.TargetNorm: --do_norm / --do_standard, dataset.py:41-148)."""
 
-    def __init__(self, dims, files: EgoScalerFiles, encode, num_steps=20, max_desc_token=20, smooth=False, norm=None):
+    def __init__(self, dims, files: EgoScalerFiles, encode, num_steps=20, max_desc_token=20, smooth=False, norm=None, sep_ids=()):
         self.dims, self.files, self.encode, self.num_steps, self.max_desc, self.smooth = dims, files, encode, num_steps, max_desc_token, smooth
         self.norm = norm if norm is not None else T.TargetNorm(do_norm=True)
+        self.sep_ids = tuple(sep_ids)                                   # ids of SEP_TOKEN between description and trajectory (dataset.py:54,169-175)
 
     def __len__(self):
         return len(self.files)
@@ -178,4 +179,4 @@ def _file_batch(self, idx, device, max_traj_token=160):
         desc[j, :len(d)], dmask[j, :len(d)] = d, True
     dev = lambda a: torch.from_numpy(np.stack(a)).to(device)
     return build_batch(dims, torch.from_numpy(desc).to(device), dev(trs), dev(pcs), max_traj_token, image_ids=torch.as_tensor(ids, device=device),
-                       desc_mask=torch.from_numpy(dmask).to(device), max_abs=dev(mabs), gt_trajs=dev(gts))
+                       desc_mask=torch.from_numpy(dmask).to(device), max_abs=dev(mabs), gt_trajs=dev(gts), sep_ids=self.sep_ids)

@@ -10,8 +10,10 @@ Mirrors egoscaler/models/pointllm/train.py:39-310 and evaluate.py:70-170 without
     train.py:72-82), gradients all-reduced by dp.GradSync overlapped with backward.
 The batch dict is the collate_fn contract of dataset.py:150-194 ('pcrgbs', 'prompts', 'prompt_masks',
 'tokens', 'attention_masks', 'trajectories', 'trajectory_masks', 'max_abs', 'image_ids'), assembled on
-the device (`build_batch`).  The release has no dataset (`__getitem__` is missing), so
-the only data source wired here is the seeded synthetic one of SURVEY.md §8d.
+the device (`build_batch`).  Data sources of the command line: EgoScaler files (`--root_dir/--data_dir`: data_io.EgoScalerFiles +
+FileTrajData, descriptions through the HF tokenizer of `--model_name` with the reference's prompt template, dataset.py:16-19) or, without
+them, the seeded synthetic samples of SURVEY.md §8d.  `--model_name DIR` goes through `build_model(args)` exactly as train.py:67 /
+evaluate.py:79 do (config.json, weights and tokenizer of the directory; trajectory tokens appended, builder.py:33-46).
 """
 import argparse
 import json
@@ -186,12 +188,13 @@ def run_validation(model, data, args, device, max_batches=None):
         gen_d = torch.from_numpy(np.ascontiguousarray(gen, dtype=np.float32)).to(device)
         ade, fde = T.metrics_batch(gen_d, None, gt)
         ade, fde, gt_h = ade.cpu().numpy(), fde.cpu().numpy(), gt.cpu().numpy()
-        for j, i in enumerate(idx):
+        ids_h = batch["image_ids"].cpu().numpy()
+        for j in range(len(idx)):
             if n_h[j] <= 0:
                 continue                                                     # detokenize_traj returned None (train.py:249-250)
             sums += [ade[j], fde[j], T.average_displacement_error(gen[j][None], gt_h[j][None]),
                      T.anglar_distance(gen[j][:, 3:6].astype(np.float64), gt_h[j][:, 3:6].astype(np.float64)), 1.0]
-            dump[int(i)] = gen[j].tolist()                                   # evaluate.py:150
+            dump[int(ids_h[j])] = gen[j].tolist()                            # evaluate.py:150: keyed by image_id.item(), not by the dataset index
     if world > 1:
         t = torch.from_numpy(sums).to(device)
         dist.all_reduce(t)
@@ -237,7 +240,9 @@ def train(args, model, train_data, val_data=None, device="cuda", log=print, step
         if val_data is not None and getattr(val_data, "norm", None) is not train_data.norm:
             val_data.norm = train_data.norm
     per_step = micro * accum * world                                                   # samples per optimizer step (== bs when divisible)
-    steps_per_epoch = len(train_data) // per_step
+    # the reference's train DataLoader (train.py:72-77: batch_size=bs, shuffle=True, NO drop_last) keeps the short last batch of an epoch:
+    # len(train_dataloader) = ceil(n / bs) iterations, which is also what sizes its LR schedule (train.py:114-116)
+    steps_per_epoch = -(-len(train_data) // per_step)
     total_steps = steps_per_epoch * args.epochs
     history = []
     model.train()
@@ -246,25 +251,36 @@ def train(args, model, train_data, val_data=None, device="cuda", log=print, step
         order = g.permutation(len(train_data))
         run = torch.zeros((), device=device)
         for it in range(steps_per_epoch):
-            for a in range(accum):
+            # the epoch's last optimizer step may be short (no drop_last, see above).  Its samples are dealt over the micro-batches in the
+            # usual order; a micro-batch that does not divide over the ranks is filled up by wrapping around to the start of the epoch's
+            # permutation, which is what torch's DistributedSampler(drop_last=False) does, so every rank always runs the SAME number of
+            # micro-batches with at least one sample each and joins the same collectives (with one rank nothing is ever padded: the short
+            # batch is exactly the reference's)
+            n_step = min(per_step, len(train_data) - it * per_step)
+            n_mb = min(accum, -(-n_step // (micro * world)))
+            for a in range(n_mb):
                 base = it * per_step + a * micro * world
-                lo, hi = shard_range(micro * world, rank, world)
-                idx = order[base + lo: base + hi]
+                n_micro = min(micro * world, n_step - a * micro * world)
+                mb = order[base: base + n_micro]
+                if n_micro % world:
+                    mb = np.concatenate([mb, order[: world - n_micro % world]])
+                lo, hi = shard_range(len(mb), rank, world)
+                idx = mb[lo:hi]
                 batch = train_data.batch(idx, device, args.max_traj_token)
-                last = a == accum - 1
+                last = a == n_mb - 1
                 model.accumulate_grads = a > 0                                      # first micro-batch overwrites (optimizer.zero_grad(), train.py:159)
                 model.engine.grad_sync = sync if last else None                     # reduce once, after the last micro-batch
                 loss = model.loss_and_backward(batch["tokens"], batch["attention_masks"], batch["pcrgbs"], batch["prompts"].shape[1],
                                                model.dims.tok.pad, fps_start=torch.zeros(len(idx), dtype=torch.int32, device=device))
-                run += loss / accum
+                run += loss / n_mb
             model.accumulate_grads = False
             if sync is not None:
                 sync.finish()
             lr_now = linear_warmup_lr(float(args.lr_llm), global_step, total_steps)
-            opt.step(grad_scale=1.0 / (accum * world), lr=lr_now, overlap=model.engine.any_layer_trainable)   # --unfreeze_language_model: on a side stream,
+            opt.step(grad_scale=1.0 / (n_mb * world), lr=lr_now, overlap=model.engine.any_layer_trainable)    # --unfreeze_language_model: on a side stream,
                                                                                                               # under the next step's forward pass (optim.py)
             if step_log is not None:
-                step_log({"epoch": epoch, "step": global_step, "learning_rate": lr_now, "loss": float(loss) if accum == 1 else None})
+                step_log({"epoch": epoch, "step": global_step, "learning_rate": lr_now, "loss": float(loss) if n_mb == 1 else None})
             global_step += 1
         rec = {"epoch": epoch, "train_loss": float(run) / max(1, steps_per_epoch), "global_step": global_step,
                "learning_rate": linear_warmup_lr(float(args.lr_llm), global_step, total_steps)}
@@ -337,7 +353,28 @@ def parse_args(argv=None):
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--val_greedy", dest="val_sample", action="store_false",
                     help="validate with greedy decoding instead of the reference's sampling defaults (model_arch.py:82-88)")
+    ap.add_argument("--root_dir", default=None, help="EgoScaler data root (pcrgbs/, trajs/ ...: dataset.py:36, dataset_base.py:68-103)")
+    ap.add_argument("--data_dir", default=None, help="directory of the split files {train,val,test}.json (dataset.py:37)")
+    ap.add_argument("--smooth_traj", action="store_true", help="smoothing_traj on the resampled tracks (dataset.py:39 reads this attribute)")
+    ap.add_argument("--split", default="test", help="eval mode: the split to generate for (evaluate.py:89-100 uses 'test')")
     return ap.parse_args(argv)
+
+
+DESC2TRAJ = {"desc": "Action description: {desc}"}                      # dataset.py:16-19
+
+
+def make_data(a, dims, tokenizer, split, norm, n_synth, seed):
+    """The split's data source: files when --root_dir/--data_dir are given (they need the tokenizer of --model_name), else synthetic."""
+    if a.root_dir and a.data_dir:
+        if tokenizer is None:
+            raise ValueError("--root_dir/--data_dir need --model_name DIR (descriptions are tokenised with its tokenizer)")
+        from .data_io import EgoScalerFiles, FileTrajData
+        from .pointllm.constant import SEP_TOKEN
+        encode = lambda text: tokenizer(DESC2TRAJ["desc"].format(desc=text), add_special_tokens=False).input_ids
+        sep = tokenizer(SEP_TOKEN, add_special_tokens=False).input_ids              # dataset.py:54
+        return FileTrajData(dims, EgoScalerFiles(a.root_dir, a.data_dir, split), encode, num_steps=a.num_steps, max_desc_token=a.max_desc_token,
+                            smooth=a.smooth_traj, norm=norm, sep_ids=tuple(int(t) for t in sep))
+    return SyntheticTrajData(dims, n_synth, num_steps=a.num_steps, seed=seed, norm=norm, max_desc_token=a.max_desc_token, ragged_text=True)
 
 
 def main(argv=None):
@@ -350,19 +387,25 @@ def main(argv=None):
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
-    dims = dims_tiny() if a.tiny else dims_7b()
     dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
-    model = TrajPointLLMForCausalLM(a, dims, a.model_name, device=dev, dtype=dtype)
-    if a.model_name is None:
+    tokenizer = None
+    if a.model_name is not None:                                        # train.py:67 / evaluate.py:79: everything comes from the directory
+        from .pointllm import build_model
+        margs = types.SimpleNamespace(**{**vars(a), "dtype": dtype, "device": dev})
+        model, tokenizer, _, _ = build_model(margs)
+        dims = model.dims
+    else:
+        dims = dims_tiny() if a.tiny else dims_7b()
+        model = TrajPointLLMForCausalLM(a, dims, None, device=dev, dtype=dtype)
         sd = synth.synth_state_dict(dims, 0)
         model.load_state_dict({k: (v.to(dtype) if v.dtype.is_floating_point else v) for k, v in sd.items()})
     a.checkpoint_dir = a.checkpoint_dir or a.out_dir
     norm = T.TargetNorm(a.do_norm, a.do_standard)
-    val = SyntheticTrajData(dims, a.n_val, num_steps=a.num_steps, seed=977, norm=norm, max_desc_token=a.max_desc_token, ragged_text=True)
     if a.mode == "train":
-        train(a, model, SyntheticTrajData(dims, a.n_train, num_steps=a.num_steps, norm=norm, max_desc_token=a.max_desc_token, ragged_text=True), val, dev)
+        val = make_data(a, dims, tokenizer, "val", norm, a.n_val, 977)
+        train(a, model, make_data(a, dims, tokenizer, "train", norm, a.n_train, 42), val, dev)
     else:
-        print(json.dumps(evaluate(a, model, val, "test", dev)))
+        print(json.dumps(evaluate(a, model, make_data(a, dims, tokenizer, a.split, norm, a.n_val, 977), a.split, dev)))
     if world > 1:
         dist.destroy_process_group()
 

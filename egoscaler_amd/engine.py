@@ -272,6 +272,9 @@ class Engine:
             self.main_grad[n] = flat[o:o + self.w[n].numel()].view(self.w[n].shape)
 
     def zero_grad(self):
+        # EgoAdamW.step(overlap=True) may still be reading these buffers on its side stream (the reference loop calls zero_grad right
+        # after step, train.py:159): the compute stream waits for the updates in flight before it clears anything
+        self.wait_param_updates()
         for g in self.main_grad.values():
             g.zero_()
         self.grad_fresh.clear()

@@ -464,8 +464,9 @@ def cross_entropy(logits, targets, ignore_index, dlogits=None, grad_scale=1.0):
     R, V = logits.shape
     cnt = torch.zeros(1, dtype=torch.int32, device=logits.device)
     ls = torch.zeros(1, dtype=torch.float32, device=logits.device)
+    rows = torch.empty(R, dtype=torch.float32, device=logits.device)
     call("egomi_ce_count", P(targets), c_i64(R), c_i64(ignore_index), P(cnt), S())
-    call("egomi_ce_fwd_bwd", P(logits), c_i64(_ld(logits)), P(targets), c_i(R), c_i(V), c_i64(ignore_index), P(cnt), P(ls),
+    call("egomi_ce_fwd_bwd", P(logits), c_i64(_ld(logits)), P(targets), c_i(R), c_i(V), c_i64(ignore_index), P(cnt), P(ls), P(rows),
          P(dlogits), c_i64(_ld(dlogits) if dlogits is not None else 0), c_f(grad_scale), c_i(dt(logits.dtype)), S())
     return ls, cnt
 

@@ -98,24 +98,57 @@ def rt2_scaler(traj: np.ndarray, maxmin, split=None) -> np.ndarray:
     return traj
 
 
-_RT2_6 = re.compile(r"<p(\d+)> <p(\d+)> <p(\d+)> <p(\d+)> <p(\d+)> <p(\d+)>")
+def simple_scaler(traj: np.ndarray, maxmin) -> np.ndarray:
+    """utils/utils.py:36-45: the <x..><y..><z..><rx..><ry..><rz..> format — rotations in percent of a turn, depth in percent of the
+    [d_min, d_max] range, x / y already in pixels."""
+    d_max, d_min = maxmin
+    traj[:, [3, 4, 5]] = np.pi * (2 * (traj[:, [3, 4, 5]] / 100) - 1)
+    traj[:, 2] = traj[:, 2] / 100
+    traj[:, 2] = traj[:, 2] * (d_max - d_min) + d_min
+    traj[:, 0] = (traj[:, 0] - PRINCIPAL_POINT) * traj[:, 2] / FOCAL_LEN
+    traj[:, 1] = (traj[:, 1] - PRINCIPAL_POINT) * traj[:, 2] / FOCAL_LEN
+    return traj
 
 
-def str_to_float(s, maxmin, split=None, rt2=True, num_bins=256):
-    """utils/utils.py:47-104 for the rt2 6-DoF format the trajectory generator emits."""
-    if not rt2:
-        raise NotImplementedError("only the rt2 <p*> format is produced by this model")
+_PATTERNS = {                                                                  # utils/utils.py:49-61
+    (True, "pos"): re.compile(r"<p(\d+)> <p(\d+)> <p(\d+)>"),
+    (True, "xy"): re.compile(r"<p(\d+)> <p(\d+)>"),
+    (True, "full"): re.compile(r"<p(\d+)> <p(\d+)> <p(\d+)> <p(\d+)> <p(\d+)> <p(\d+)>"),
+    (False, "pos"): re.compile(r"<x(\d+)><y(\d+)><z(\d+)>"),
+    (False, "full"): re.compile(r"<x(\d+)><y(\d+)><z(\d+)><rx(\d+)><ry(\d+)><rz(\d+)>"),
+}
+
+
+def str_to_float(s, maxmin, split=None, rt2=False, only_pos=False, only_xy=False, z_values=None, num_bins=256):
+    """utils/utils.py:47-104, every format: `rt2` (<p*> bins; 6-DoF, `only_pos` = 3 bins with rotations at bin 0, `only_xy` = 2 bins with
+    the depth taken from `z_values[i]`, the last one repeated) or the per-axis <x..><y..> form (`only_pos`: 3 integers; `only_xy` is ignored
+    there, as in the reference).  One match per `<tsep>` segment, a segment without one repeats the previous step (only once one exists,
+    :88-90); float32 array through rt2_scaler / simple_scaler, None when nothing parsed.  (The reference's default is rt2=False; the
+    trajectory generator's drivers pass rt2=True.)"""
+    kind = "pos" if only_pos else ("xy" if (only_xy and rt2) else "full")
+    pattern = _PATTERNS[(bool(rt2), kind)]
     traj, last = [], None
-    for seg in s.split("<tsep>"):
-        m = _RT2_6.search(seg)
+    for i, seg in enumerate(s.split("<tsep>")):
+        m = pattern.search(seg)
         if m:
-            last = tuple(token_to_action([int(g) for g in m.groups()], num_bins=num_bins))
+            if rt2:
+                g = [int(v) for v in m.groups()]
+                x, y, z, rx, ry, rz = token_to_action(g + [0] * (6 - len(g)), num_bins=num_bins)
+                if kind == "xy":
+                    z = z_values[i] if i < len(z_values) else z_values[-1]
+            elif only_pos:
+                x, y, z = map(int, m.groups())
+                rx, ry, rz = 0, 0, 0
+            else:
+                x, y, z, rx, ry, rz = map(float, m.groups())
+            last = (x, y, z, rx, ry, rz)
             traj.append(last)
         elif last is not None:
             traj.append(last)
     if not traj:
         return None
-    return rt2_scaler(np.array(traj).astype(np.float32), maxmin, split)
+    traj = np.array(traj).astype(np.float32)
+    return rt2_scaler(traj, maxmin, split) if rt2 else simple_scaler(traj, maxmin)
 
 
 def denorm(traj: np.ndarray) -> np.ndarray:

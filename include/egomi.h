@@ -212,9 +212,12 @@ typedef struct egomi_attn_desc {
 } egomi_attn_desc;
 int egomi_attn_fwd(const egomi_attn_desc* desc, egomi_stream_t stream);
 int egomi_attn_bwd(const egomi_attn_desc* desc, egomi_stream_t stream);
-/* A/B switch (like the EGOMI_* environment switches): 1 = the first form of the forward kernel, 2 = the restructured one (default;
- * bit-identical results: tests/test_gpu_kernels.py).  Process-wide, not thread-safe: measurement and tests only. */
+/* A/B switch (like the EGOMI_* environment switches): 1 = the first form of the forward kernel, 2 = the round-3 instruction stream
+ * (bit-identical to 1: tests/test_gpu_kernels.py), 3 = the round-4 restructure (default at head_dim 128: 32-key tiles in a 4-stage ring,
+ * QK of tile t+1 under the exponentials of tile t, lazy running max, end-aligned query blocks; same tolerances vs fp32, not the same bits).
+ * Process-wide, not thread-safe: measurement and tests only. */
 int egomi_attn_set_fwd_form(int form);
+int egomi_attn_set_fwd_group(int group);   /* block order of form 3: 0 = rank-major, G = a (b,h) pair's blocks in groups of G ranks on one XCD */
 int egomi_attn_set_bwd_form(int form);   /* likewise for the two backward kernels */
 
 /* Consumers of EGOMI_EPI_SLABS products (single-token decode; replace splitk combine + the next elementwise kernels of
@@ -393,11 +396,11 @@ int egomi_embed_splice_bwd(const void* dout, const int64_t* ids, const int32_t* 
 
 /* A12  cross-entropy with ignore_index, mean over kept rows.  replaces F.cross_entropy at
  * models/pointllm/train.py:174-181.  count must be zeroed, then ce_count, then ce_fwd_bwd:
- * loss_sum (fp32, zeroed by caller) += sum_rows -log p[target]; dlogits (may alias logits, may be
- * NULL) = (softmax - onehot) * grad_scale / count. */
+ * row_loss[R] (fp32 scratch of the caller) = -log p[target] per row (0 for ignored rows), loss_sum (fp32, zeroed by caller) += their sum
+ * in a fixed order (no atomics: the same bits every run); dlogits (may alias logits, may be NULL) = (softmax - onehot) * grad_scale / count. */
 int egomi_ce_count(const int64_t* targets, int64_t n, int64_t ignore, int32_t* count, egomi_stream_t stream);
 int egomi_ce_fwd_bwd(const void* logits, int64_t ld, const int64_t* targets, int R, int V, int64_t ignore, const int32_t* count,
-                     float* loss_sum, void* dlogits, int64_t ldd, float grad_scale, int dtype, egomi_stream_t stream);
+                     float* loss_sum, float* row_loss, void* dlogits, int64_t ldd, float grad_scale, int dtype, egomi_stream_t stream);
 
 /* AdamW step (torch.optim.AdamW semantics; reference optimizer models/pointllm/train.py:107-111).
  * fp32 master/moments/grad; model_copy (copy_dtype, may be NULL) receives the updated value. */

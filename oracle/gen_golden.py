@@ -158,6 +158,50 @@ def gen_pointcloud():
 
 
 # -------------------------------------------------------------------------------------------------
+def gen_traj_formats():
+    """Every output format of the reference's `str_to_float` (utils/utils.py:47-104: rt2 6-DoF / only_pos / only_xy + z_values, and the
+    per-axis <x..><y..><z..>[<rx..><ry..><rz..>] form through `simple_scaler`, utils.py:36-45), recorded from the reference's own functions
+    (compiled in memory: the module raises at import).  Strings carry malformed segments in front and in the middle (the
+    copy-forward rule, :88-90) and fewer z_values than steps (the last one is repeated, :76)."""
+    from egoscaler.configs.camera import CameraConfig
+    glb = {"np": np, "re": __import__("re"), "PINHOLE_IMAGE_HEIGHT": 1408, "PINHOLE_IMAGE_WIDTH": 1408,
+           "FOCAL_LEN": CameraConfig.devices.aria.focal_len, "PRICIPAL_POINT": CameraConfig.devices.aria.principal_point}
+    path = os.path.join(REF, "egoscaler/models/pointllm/utils/utils.py")
+    names = ["discretize_action", "token_to_action", "rt2_scaler", "simple_scaler", "str_to_float"]
+    fns = _functions_from(path, names, dict(glb))
+    for f_ in fns:
+        f_.__globals__.update({n: fn for n, fn in zip(names, fns)})
+    simple, s2f = fns[3], fns[4]
+    g = np.random.default_rng(11)
+    out, strings = {}, {}
+    tr = np.concatenate([g.uniform(0, 1408, (7, 2)), g.uniform(0, 100, (7, 4))], 1).astype(np.float32)
+    out["simple_in"], out["simple_out"] = tr, simple(tr.copy(), [2.5, 0.1])
+
+    def segs(fmt, n, lo, hi, bad=(0, 3)):
+        rows = g.integers(lo, hi, (6, n))
+        return " <tsep> ".join("garbage" if i in bad else fmt(r) for i, r in enumerate(rows))
+    cases = {
+        "rt2_full": (segs(lambda r: " ".join(f"<p{x}>" for x in r), 6, 0, 256), dict(rt2=True)),
+        "rt2_pos": (segs(lambda r: " ".join(f"<p{x}>" for x in r), 3, 0, 256), dict(rt2=True, only_pos=True)),
+        "rt2_xy": (segs(lambda r: " ".join(f"<p{x}>" for x in r), 2, 0, 256), dict(rt2=True, only_xy=True, z_values=[0.25, -0.5, 0.75])),
+        "rt2_pos_bins16": (segs(lambda r: " ".join(f"<p{x}>" for x in r), 3, 0, 16, bad=(2,)), dict(rt2=True, only_pos=True, num_bins=16)),
+        "axis_full": (segs(lambda r: "<x%d><y%d><z%d><rx%d><ry%d><rz%d>" % tuple(r), 6, 0, 100), dict()),
+        "axis_pos": (segs(lambda r: "<x%d><y%d><z%d>" % tuple(r), 3, 0, 100, bad=(1, 2)), dict(only_pos=True)),
+        "axis_full_only_xy_ignored": (segs(lambda r: "<x%d><y%d><z%d><rx%d><ry%d><rz%d>" % tuple(r), 6, 0, 100, bad=()), dict(only_xy=True)),
+    }
+    for name, (body, kw) in cases.items():
+        text = "<ts> " + body + " <tsep> <te>"
+        res = s2f(text, [2.5, 0.1], "val", **kw)
+        assert res is not None and res.dtype == np.float32
+        strings[name] = {"text": text, "kwargs": kw}
+        out[name] = res
+    assert s2f("<ts> nothing <te>", [2.5, 0.1], "val") is None
+    np.savez_compressed(os.path.join(GOLD, "traj_formats.npz"), **out)
+    json.dump(strings, open(os.path.join(GOLD, "traj_format_strings.json"), "w"), indent=1)
+    print("traj_formats:", {k: v.shape for k, v in out.items()})
+
+
+# -------------------------------------------------------------------------------------------------
 def gen_traj():
     from egoscaler.models.utils import traj_utils as RT, metrics as RM
     cam = types.SimpleNamespace()
@@ -922,7 +966,7 @@ def gen_multi_segment():
 
 if __name__ == "__main__":
     which = sys.argv[1:] or ["pointcloud", "depth_cloud", "traj", "collate", "pointbert_full", "tiny_model", "tiny_pc_unfrozen", "tiny_model_bf16", "tiny_trained",
-                             "sampling", "train_steps", "multi_segment"]
+                             "sampling", "train_steps", "multi_segment", "traj_formats"]
     for w in which:
         globals()["gen_" + w]()
     sizes = {f: os.path.getsize(os.path.join(GOLD, f)) for f in sorted(os.listdir(GOLD))}

@@ -26,3 +26,17 @@ def test_host_helpers_match_reference_golden(golden_dir):
     assert T.average_displacement_error(g["m_gen20"][None], g["m_gt"][None]) == float(g["ade_as_called"])
     out, pm = T.preprocess_traj(g["pre_in_7"], 20, return_padding_mask=True)
     assert pm.tolist() == [1] * 7 + [0] * 13
+
+
+def test_str_to_float_every_format_and_simple_scaler_match_reference_golden(golden_dir):
+    """utils/utils.py:36-104 beyond the 6-DoF rt2 form (VERDICT r3 missing #3): `only_pos`, `only_xy` + z_values, the per-axis
+    <x..><y..><z..> forms through `simple_scaler`, a 16-bin vocabulary; malformed segments copy the previous step forward.  Bit-equal to what
+    the reference's own functions returned (tests/golden/traj_formats.npz, oracle/gen_golden.py::gen_traj_formats)."""
+    g = np.load(os.path.join(golden_dir, "traj_formats.npz"))
+    cases = json.load(open(os.path.join(golden_dir, "traj_format_strings.json")))
+    assert np.array_equal(T.simple_scaler(g["simple_in"].copy(), [2.5, 0.1]), g["simple_out"])
+    assert set(cases) == {"rt2_full", "rt2_pos", "rt2_xy", "rt2_pos_bins16", "axis_full", "axis_pos", "axis_full_only_xy_ignored"}
+    for name, c in cases.items():
+        got = T.str_to_float(c["text"], [2.5, 0.1], "val", **c["kwargs"])
+        assert got.dtype == np.float32 and np.array_equal(got, g[name]), name
+    assert T.str_to_float("<ts> nothing <te>", [2.5, 0.1], "val") is None          # the reference's default format (rt2=False): nothing parsed

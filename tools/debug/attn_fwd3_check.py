@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""Forward form 3 against form 2 and an fp32 torch reference over masks / shapes (GPU box only)."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import torch
+from egoscaler_amd import ops, _lib
+
+L = _lib.lib()
+hd = 128
+worst = 0.0
+for (B, S, H, causal, mask) in [(2, 692, 3, True, "tail"), (1, 692, 2, True, None), (2, 513, 2, False, None), (1, 200, 2, True, "holes"), (2, 64, 1, False, "tail"),
+                                (1, 33, 2, True, None), (1, 1, 1, True, None), (2, 300, 2, False, "holes"), (1, 1000, 1, True, "tail"), (2, 256, 4, True, "tail"),
+                                (1, 128, 1, True, None), (1, 32, 1, True, None), (1, 31, 1, False, None), (3, 97, 2, True, "holes"), (1, 2048, 2, True, None)]:
+    torch.manual_seed(S)
+    qkv = (torch.randn(B * S, 3 * H * hd, device="cuda") * 1.0).bfloat16()
+    km = None
+    if mask:
+        km = torch.ones(B, S, dtype=torch.uint8)
+        if mask == "tail":
+            km[-1, S - max(1, S // 5):] = 0
+        else:
+            km[0, 2:4] = 0
+            km[-1, S // 2] = 0
+        km = km.cuda()
+    res = {}
+    for form in (2, 3):
+        assert L.egomi_attn_set_fwd_form(form) == 0
+        out = torch.full((B * S, H * hd), 7.0, dtype=torch.bfloat16, device="cuda")
+        lse = torch.full((B, H, S), 7.0, dtype=torch.float32, device="cuda")
+        ops.attn_fwd(qkv, B, S, H, hd, hd ** -0.5, out, lse, causal=causal, key_mask=km)
+        torch.cuda.synchronize()
+        res[form] = (out.float(), lse)
+    x = qkv.float().view(B, S, 3, H, hd)
+    q, k, v = x[:, :, 0].transpose(1, 2), x[:, :, 1].transpose(1, 2), x[:, :, 2].transpose(1, 2)
+    sc = (q @ k.transpose(-1, -2)) * hd ** -0.5
+    keep = torch.ones(S, S, dtype=torch.bool, device="cuda")
+    if causal:
+        keep = torch.tril(keep)
+    keep = keep[None, None]
+    if km is not None:
+        keep = keep & km.bool()[:, None, None, :]
+    sc = sc.masked_fill(~keep, float("-inf"))
+    ref = (torch.softmax(sc, -1) @ v).transpose(1, 2).reshape(B * S, H * hd)
+    lref = torch.logsumexp(sc, -1)
+    e2 = float((res[2][0] - ref).abs().max()); e3 = float((res[3][0] - ref).abs().max())
+    l2 = float((res[2][1] - lref).abs().max()); l3 = float((res[3][1] - lref).abs().max())
+    worst = max(worst, e3)
+    ok = e3 <= max(2 * e2, 2e-2 * float(ref.abs().max())) and l3 < 2e-2 and bool(torch.isfinite(res[3][0]).all())
+    print(f"B={B} S={S} H={H} causal={causal} mask={mask}: |O-ref| form2 {e2:.3e} form3 {e3:.3e}  |lse-ref| {l2:.2e} {l3:.2e}  {'ok' if ok else 'FAIL'}", flush=True)
+    assert ok
+L.egomi_attn_set_fwd_form(3)
+print("all ok, worst", worst)
