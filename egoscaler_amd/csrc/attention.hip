@@ -1185,15 +1185,17 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq2_kernel(AttnArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     int rank, h, b;
     attn_block_map(a, rank, h, b);
-    const int q0 = ((a.S + 127) / 128 - 1 - rank) * 128;
-    const bool wave_dead = q0 + wave * 32 >= a.S;
+    // query blocks aligned to the END of the sequence rounded up to 32 (round 4, as attn_fwd3_kernel): the ragged block is the first,
+    // shortest one instead of the last (S = 692: 36 instead of 41 tile-steps per (b, h) pair); rows q < 0 are dead lanes / dead waves.
+    // Every row still meets the same 64-key tiles in the same order: results are unchanged bit for bit.
+    const int q0 = ((a.S + 31) & ~31) - 128 * (rank + 1);
     const long long row_base = (long long)b * a.S;
     const bf16_t* Q = a.q + row_base * a.ld_qkv + h * AT_HD;
     const bf16_t* K = a.k + row_base * a.ld_qkv + h * AT_HD;
     const bf16_t* V = a.v + row_base * a.ld_qkv + h * AT_HD;
     const bf16_t* DO = a.dout + row_base * a.ld_o + h * AT_HD;
     const int qi = q0 + wave * 32 + (lane & 31);
-    const int qr = qi < a.S ? qi : a.S - 1;
+    const int qr = qi < 0 ? 0 : (qi < a.S ? qi : a.S - 1);
     int last = q0 + 127 < a.S - 1 ? q0 + 127 : a.S - 1;
     const int ntiles = a.causal ? (last / 64 + 1) : ((a.S + 63) / 64);
     const bool ragged = ntiles * 64 > a.S;
@@ -1253,7 +1255,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq2_kernel(AttnArgs a) {
             for (int e = 0; e < 8; ++e) dlt = fmaf((float)dof[ks][e], (float)of[e], dlt);
         }
         dlt += __shfl_xor(dlt, 32, 64);
-        if (half == 0 && qi < a.S) a.delta[st] = dlt;
+        if (half == 0 && qi >= 0 && qi < a.S) a.delta[st] = dlt;
     }
     const float sc2 = a.scale * 1.4426950408889634f;
 #pragma unroll
@@ -1267,9 +1269,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq2_kernel(AttnArgs a) {
         for (int r = 0; r < 16; ++r) dq[dt][r] = 0.f;
 
     const int wave_q0 = q0 + wave * 32;
-    int n_live = wave_dead ? 0 : (a.causal ? (wave_q0 + 31) / 64 + 1 : ntiles);
+    const int wl = wave_q0 + 31 < a.S - 1 ? wave_q0 + 31 : a.S - 1;   // the wave's last live query (< 0: none)
+    const int wf = wave_q0 < 0 ? 0 : wave_q0;
+    int n_live = wl < 0 ? 0 : (a.causal ? wl / 64 + 1 : ntiles);
     n_live = n_live < ntiles ? n_live : ntiles;
-    int n_int = a.causal ? (wave_q0 >= 63 ? (wave_q0 - 63) / 64 + 1 : 0) : ntiles;
+    int n_int = a.causal ? (wf >= 63 ? (wf - 63) / 64 + 1 : 0) : ntiles;
     n_int = n_int < n_live ? n_int : n_live;
     if (a.S % 64 && n_int == ntiles) n_int = ntiles - 1;
 
@@ -1323,6 +1327,154 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq2_kernel(AttnArgs a) {
         end_of_tile();
     }
     store_rows_via_lds(smem + wave * AT_XBYTES, dq, a.scale, a.dq + row_base * a.ld_dqkv + h * AT_HD, a.ld_dqkv, q0 + wave * 32, a.S, lane,
+                       a.rope_cos, a.rope_sin);
+}
+
+// =================================================================================================
+// backward 1/2, third form (round 4, default; EGOMI_ATTN_BWD=2 / egomi_attn_set_bwd_form(2) select the second form for A/B runs): the arithmetic
+// of attn_bwd_dq2_kernel per 32-key tile (dq2_subtile, unchanged: results stay bit-identical) on attn_fwd3_kernel's data path — 32-key
+// tiles in a 4-stage LDS ring, tile t+3 requested at the top of tile t, ONE barrier per 32 keys with nothing waiting for a DMA younger than
+// two tiles (the second form met two barriers per 64 keys and waited for the DMA it had issued one tile earlier) — and query blocks aligned
+// to the end of the sequence.  The intra-wave pipeline of the forward (scores of tile t+1 under the exponentials of tile t) does not fit here:
+// x and dP of two tiles next to dQ, Q and dO fragments are 264 registers, and two blocks per CU is worth more.
+// =================================================================================================
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq3_kernel(AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];       // [4 stages][K 8 KB | V 8 KB] + key mask bytes
+    char* sMask = smem + F3_NST * F3_STAGE;
+    const int lane = threadIdx.x & 63, half = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int rank, h, b;
+    attn_block_map(a, rank, h, b);
+    const int q0 = ((a.S + 31) & ~31) - 128 * (rank + 1);
+    const long long row_base = (long long)b * a.S;
+    const bf16_t* Q = a.q + row_base * a.ld_qkv + h * AT_HD;
+    const bf16_t* K = a.k + row_base * a.ld_qkv + h * AT_HD;
+    const bf16_t* V = a.v + row_base * a.ld_qkv + h * AT_HD;
+    const bf16_t* DO = a.dout + row_base * a.ld_o + h * AT_HD;
+    const int wave_q0 = q0 + wave * 32;
+    const int qi = wave_q0 + (lane & 31);
+    const int qr = qi < 0 ? 0 : (qi < a.S ? qi : a.S - 1);
+    const int last = q0 + 127 < a.S - 1 ? q0 + 127 : a.S - 1;
+    const int nkt = (a.S + F3_KT - 1) / F3_KT;
+    const int ntiles = a.causal ? last / F3_KT + 1 : nkt;
+    uint32_t koff[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int rl = (wave * 2 + j) * 4 + (lane >> 4);
+        const int ch = (lane & 15) ^ (((rl & 3) << 2) | ((rl >> 2) & 3));
+        const int r = rl < a.S ? rl : a.S - 1;
+        koff[j] = (uint32_t)((long long)r * a.ld_qkv + ch * 8) * 2u;
+    }
+    const uint32_t tile_stride = (uint32_t)(F3_KT * a.ld_qkv * 2);
+    const uint32_t lds0 = (uint32_t)(uintptr_t)((lds_void_t*)smem) + wave * 2 * 1024;
+    int next_req = 0;
+    auto request = [&]() {
+        const uint32_t base = __builtin_amdgcn_readfirstlane(lds0 + (next_req & (F3_NST - 1)) * F3_STAGE);
+        if ((next_req + 1) * F3_KT <= a.S) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) dma16_asm(K, koff[j], base + j * 1024);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) dma16_asm(V, koff[j], base + F3_TB + j * 1024);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) koff[j] += tile_stride;
+        } else {
+            uint32_t off[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int rl = (wave * 2 + j) * 4 + (lane >> 4);
+                const int ch = (lane & 15) ^ (((rl & 3) << 2) | ((rl >> 2) & 3));
+                int r = next_req * F3_KT + rl;
+                r = r < a.S ? r : a.S - 1;
+                off[j] = (uint32_t)((long long)r * a.ld_qkv + ch * 8) * 2u;
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) dma16_asm(K, off[j], base + j * 1024);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) dma16_asm(V, off[j], base + F3_TB + j * 1024);
+        }
+        ++next_req;
+    };
+    request();
+    if (ntiles > 1) request();
+    uint8_t mv[AT_MASK_IT];
+    mask_fetch(a, row_base, ntiles * F3_KT, mv);
+    bf16x8 qf[8], dof[8];
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+        qf[ks] = *reinterpret_cast<const bf16x8*>(Q + (long long)qr * a.ld_qkv + 16 * ks + 8 * half);
+        dof[ks] = *reinterpret_cast<const bf16x8*>(DO + (long long)qr * a.ld_o + 16 * ks + 8 * half);
+    }
+    const long long st = ((long long)b * a.H + h) * a.S + qr;
+    const float lse2 = a.lse[st] * 1.4426950408889634f;
+    float dlt = 0.f;                                                   // delta[b,h,q] = sum_d dO[q,d] * O[q,d] (see attn_bwd_dq_kernel)
+    {
+        const bf16_t* Orow = a.o + (row_base + qr) * a.ld_o + h * AT_HD;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            const bf16x8 of = *reinterpret_cast<const bf16x8*>(Orow + 16 * ks + 8 * half);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) dlt = fmaf((float)dof[ks][e], (float)of[e], dlt);
+        }
+        dlt += __shfl_xor(dlt, 32, 64);
+        if (half == 0 && qi >= 0 && qi < a.S) a.delta[st] = dlt;
+    }
+    const float sc2 = a.scale * 1.4426950408889634f;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) asm volatile("" :: "v"(qf[ks]), "v"(dof[ks]));
+    asm volatile("" :: "v"(lse2), "v"(dlt));
+    mask_commit(a, row_base, ntiles * F3_KT, mv, sMask);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // tiles 0 and 1 (and the delta store) are done
+    if (ntiles > 2) request();                                         // tile 2 stays in flight across the barrier
+    f32x16 dq[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dq[dt][r] = 0.f;
+
+    const int wl = wave_q0 + 31 < a.S - 1 ? wave_q0 + 31 : a.S - 1;
+    const int wf = wave_q0 < 0 ? 0 : wave_q0;
+    int n_live = wl < 0 ? 0 : (a.causal ? wl / F3_KT + 1 : ntiles);
+    n_live = n_live < ntiles ? n_live : ntiles;
+    int n_int = a.causal ? (wf >= F3_KT - 1 ? (wf - (F3_KT - 1)) / F3_KT + 1 : 0) : ntiles;
+    n_int = n_int < n_live ? n_int : n_live;
+    if (a.S % F3_KT && n_int == nkt) n_int = nkt - 1;
+
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                                      // tiles 0, 1 and the mask bytes are in LDS for every wave
+    // top of tile t: tile t has landed for everybody (tiles t+1, t+2 may still be in flight), stage (t+3) % 4 = tile t-1's is free: request tile t+3
+    auto top = [&](int t) {
+        if (t > 0) {
+            const int ahead = ntiles - 1 - t;                          // tiles after t that have been requested: min(ahead, 2)
+            if (ahead >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else if (ahead == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+        if (t + 3 < ntiles) request();
+    };
+    auto kbits = [&](int t) -> uint32_t { return (uint32_t)__ballot(sMask[t * F3_KT + (lane & 31)] != 0); };
+    int t = 0;
+    bool carried = false;
+    uint32_t km = 0u;
+    for (; t < n_int; ++t) {
+        top(t);
+        km = kbits(t);
+        if (km != 0xFFFFFFFFu) { carried = true; break; }
+        const char* sK = smem + (t & 3) * F3_STAGE;
+        dq2_subtile<false>(sK, sK + F3_TB, 0, qf, dof, dq, sc2, lse2, dlt, 0u, lane, half);
+    }
+    for (; t < n_live; ++t) {
+        if (!carried) { top(t); km = kbits(t); }
+        carried = false;
+        const char* sK = smem + (t & 3) * F3_STAGE;
+        const uint32_t v0 = visible_bits(km, half, t * F3_KT, qi, a.causal);
+        dq2_subtile<true>(sK, sK + F3_TB, 0, qf, dof, dq, sc2, lse2, dlt, v0, lane, half);
+    }
+    for (; t < ntiles; ++t) top(t);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                                      // nobody reads a stage any more: the ring becomes the epilogue's strips
+    store_rows_via_lds(smem + wave * AT_XBYTES, dq, a.scale, a.dq + row_base * a.ld_dqkv + h * AT_HD, a.ld_dqkv, wave_q0, a.S, lane,
                        a.rope_cos, a.rope_sin);
 }
 
@@ -1728,11 +1880,11 @@ extern "C" int egomi_attn_set_fwd_group(int group) {
 }
 static int g_attn_bwd_form = -1;
 static int attn_bwd_form() {
-    if (g_attn_bwd_form < 0) { const char* e = getenv("EGOMI_ATTN_BWD"); g_attn_bwd_form = e ? atoi(e) : 2; }
+    if (g_attn_bwd_form < 0) { const char* e = getenv("EGOMI_ATTN_BWD"); g_attn_bwd_form = e ? atoi(e) : 3; }
     return g_attn_bwd_form;
 }
 extern "C" int egomi_attn_set_bwd_form(int form) {
-    if (form != 1 && form != 2) return EGOMI_E_BADARG;
+    if (form < 1 || form > 3) return EGOMI_E_BADARG;
     g_attn_bwd_form = form;
     return EGOMI_OK;
 }
@@ -1818,7 +1970,11 @@ extern "C" int egomi_attn_bwd(const egomi_attn_desc* d, egomi_stream_t stream) {
     const size_t lds_q = ((occ_dq2() ? 2 : 3) * 2 * 64 * 256) + (size_t)((d->S + 63) / 64) * 64;
     const int occ = attn_occ();
     const bool off32 = (long long)d->S * d->ld_qkv * 2 < (1ll << 32) && (long long)d->S * d->ld_o * 2 < (1ll << 32);     // the second forms address rows with 32-bit byte offsets
-    if ((occ & 1) && attn_bwd_form() == 2 && off32) {
+    if ((occ & 1) && attn_bwd_form() == 3 && off32) {
+        const size_t lds3 = (size_t)F3_NST * F3_STAGE + (size_t)((d->S + 31) & ~31);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
+        EGOMI_LAUNCH(attn_bwd_dq3_kernel, grid, dim3(256), lds3, s, a);
+    } else if ((occ & 1) && attn_bwd_form() == 2 && off32) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q);
         EGOMI_LAUNCH(attn_bwd_dq2_kernel, grid, dim3(256), lds_q, s, a);
     } else if (occ & 1) {
@@ -1829,7 +1985,7 @@ extern "C" int egomi_attn_bwd(const egomi_attn_desc* d, egomi_stream_t stream) {
         EGOMI_LAUNCH(attn_bwd_dq_kernel<1>, grid, dim3(256), lds_q, s, a);
     }
     const size_t lds_k = (occ & 2) ? 2 * DKV_STAGE + 128 * 256 : 3 * DKV_STAGE;
-    if ((occ & 2) && attn_bwd_form() == 2 && off32) {
+    if ((occ & 2) && attn_bwd_form() >= 2 && off32) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkdv2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_k);
         EGOMI_LAUNCH(attn_bwd_dkdv2_kernel, grid, dim3(256), lds_k, s, a);
     } else if (occ & 2) {

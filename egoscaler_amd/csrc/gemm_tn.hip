@@ -63,7 +63,11 @@ struct TnSide {
                     const int r = piece * 4 + (lane >> 4);                        // k-row of the image
                     const int ch = (lane & 15) ^ (((r & 3) << 2) | ((r >> 2) & 3));
                     long long col = rows0 + 128 * h + 8 * ch;
-                    col = col < ld - 8 ? col : ld - 8;                          // stay inside the row (out-of-range outputs are masked on store)
+                    // stay inside the OPERAND's own width, not the row stride: a column-sliced view (dgu[:, Fd:], dqkv[:, 2d:]) starts inside a
+                    // wider row, so `ld - 8` from its base runs past the row end, and on the last reduction row past the END of the allocation
+                    // (the class of the dK/dV over-read of round 3).  Out-of-range outputs are masked on store.
+                    const long long lim = (long long)((nrows + 7) & ~7) - 8;
+                    col = col < lim ? col : lim;
                     voff[h][i] = (uint32_t)(((long long)r * ld + col) * 2);
                 } else {
                     const int lr = piece * 8 + (lane >> 3);                       // row of the image = tile row 128 h + lr
@@ -337,6 +341,9 @@ static bool tn_applicable(const egomi_gemm_desc* d) {
     if ((d->lda & 7) || (d->ldb & 7) || (((uintptr_t)d->A | (uintptr_t)d->B) & 15)) return false;
     if (d->a_layout == 1 ? d->lda < 8 : d->lda < d->K) return false;
     if (d->ldb < 8) return false;
+    // a k-major operand's 16-B DMA chunks are clamped to its own width rounded up to 8 (TnSide::init): that stays inside the operand's row —
+    // also for a column slice of a wider array, whose base and row stride are multiples of 8 elements — as long as the row is that long
+    if (d->ldb < ((d->N + 7) & ~7) || (d->a_layout == 1 && d->lda < ((d->M + 7) & ~7))) return false;
     const int esz = d->c_dtype == EGOMI_BF16 ? 2 : 4;
     if ((uintptr_t)d->C % (4 * esz)) return false;
     // 32-bit byte offsets inside one K-tile's rows (+ the tile's columns)

@@ -57,6 +57,7 @@ class Engine:
         self.trainable: Dict[str, bool] = {}
         self.ctx = None
         self.grad_sync = None          # optional dp.GradSync: notified when a gradient buffer is final
+        self.pb_drop_override = None   # DropPath branch scales for the NEXT train-mode point-backbone pass instead of fresh draws (parity tests)
         self.reduced_grad = {}         # resident exchange (dp.GradSync(resident=True)): name -> bf16 view of the rank-summed gradient in the
         self.layer_offs = {}           # layer's wire buffer, read by EgoAdamW; layer_offs[l][name] = element offset inside the layer's flat block
         self._direct, self._direct_done = None, set()
@@ -419,8 +420,9 @@ class Engine:
                 from .pointbert_train import PointBackboneTrainer
                 if self.pb_trainer is None:
                     self.pb_trainer = PointBackboneTrainer(self)
-                feats, pb_ctx = self.pb_trainer.forward(point_clouds.to(self.device, torch.float32), fps_start,
-                                                        self.pb_trainer.drop_scales(point_clouds.shape[0]))
+                drop = self.pb_drop_override if self.pb_drop_override is not None else self.pb_trainer.drop_scales(point_clouds.shape[0])
+                self.pb_drop_override = None                # one forward pass only (tests hand in recorded DropPath draws: [depth, 2, B] scales)
+                feats, pb_ctx = self.pb_trainer.forward(point_clouds.to(self.device, torch.float32), fps_start, drop)
                 ctx["pb_ctx"] = pb_ctx
                 self.prepared_bn_stale = True
             else:

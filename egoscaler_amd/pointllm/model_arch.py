@@ -8,6 +8,7 @@ so checkpoints round-trip.  All arithmetic runs in egoscaler_amd.engine on libeg
 """
 import json
 import os
+import types
 from dataclasses import dataclass
 from typing import List, Optional, Tuple
 
@@ -245,6 +246,7 @@ class TrajPointLLMForCausalLM(nn.Module):
                     "projection_hidden_dim": list(pb.projection_hidden_dim), "use_max_pool": False})     # pointllm.py:49-59
         self.point_backbone_config = cfg
         self.model.point_backbone_config = cfg
+        self.model.load_point_backbone_checkpoint = self.load_point_backbone_checkpoint     # the reference calls it on get_model() (pointllm.py:86)
 
     def get_model(self):
         return self.model
@@ -282,6 +284,35 @@ class TrajPointLLMForCausalLM(nn.Module):
                 sd.update(torch.load(os.path.join(self.model_name, f), map_location="cpu", weights_only=True))
         if sd:
             self.load_state_dict(sd, strict=False)
+
+    def load_point_backbone_checkpoint(self, checkpoint_path=None):
+        """pointllm.py:86-87 -> PointTransformer.load_checkpoint (point_encoder.py:144-166): a PointBERT pre-training checkpoint, `torch.save`d as
+        {'state_dict': {...}}; the keys prefixed `module.point_encoder.` are the encoder's own state dict and are loaded non-strictly, every
+        other key of the file (classification heads, the dVAE) is ignored.  Returns the (missing_keys, unexpected_keys) the reference prints.
+        The file is read with weights_only=True: nothing in it can execute."""
+        path = checkpoint_path if checkpoint_path is not None else getattr(self.config, "point_backbone_ckpt", None)
+        if path is None:
+            raise ValueError("no checkpoint path: pass one or set config.point_backbone_ckpt")
+        ckpt = torch.load(path, map_location="cpu", weights_only=True)
+        pre, dst = "module.point_encoder.", "model.point_backbone."
+        src = {k[len(pre):]: v for k, v in ckpt["state_dict"].items() if k.startswith(pre)}
+        own = {k[len(dst):]: v for k, v in super().state_dict().items() if k.startswith(dst)}
+        self.engine.wait_param_updates()
+        with torch.no_grad():
+            for k, v in src.items():
+                if k in own:
+                    if own[k].shape != v.shape:
+                        raise RuntimeError(f"size mismatch for {k}: copying a param with shape {tuple(v.shape)} from checkpoint, "
+                                           f"the shape in current model is {tuple(own[k].shape)}.")      # load_state_dict raises on shapes even when not strict
+                    own[k].copy_(v)
+        missing = [k for k in own if k not in src]
+        unexpected = [k for k in src if k not in own]
+        self.engine.prepared = False                        # BatchNorm fold / stacked copies follow the loaded values
+        if not missing and not unexpected:
+            print(f"PointBERT's weights are successfully loaded from {path}")
+        else:
+            print("missing_keys", missing, "unexpected_keys", unexpected)
+        return types.SimpleNamespace(missing_keys=missing, unexpected_keys=unexpected)
 
     def save_pretrained(self, path):
         from safetensors.torch import save_file

@@ -573,6 +573,82 @@ def gen_tiny_pc_unfrozen():
     RPL.cfg_from_yaml_file = orig_cfg
 
 
+def gen_tiny_pc_unfrozen_droppath():
+    """--unfreeze_pc_encoder with stochastic depth ON: the YAML's DropPath (point_encoder.py:65,133-134; rates
+    linspace(0, drop_path_rate, depth)) in train() mode.  The per-sample 0/1 draws are handed to the DropPath stand-in (oracle/_shims/timm:
+    timm 0.4.12's arithmetic, the draw taken from `MASKS`) and recorded in the fixture; the product receives the same draws as branch scales.
+    depth 2, rate 0.5: block 0 runs at p = 0 (identity, consumes no draw), block 1 at p = 0.5 — attention branch, then MLP branch."""
+    import pointllm.model.pointllm as RPL
+    from pointllm.model import PointLLMLlamaForCausalLM, PointLLMConfig
+    import model_arch as RMA
+    import timm.models.layers as TL
+    dims = dims_tiny()
+    dims.pb.drop_path_rate = 0.5
+    lm, pb, tok = dims.lm, dims.pb, dims.tok
+    orig_cfg = RPL.cfg_from_yaml_file
+    RPL.cfg_from_yaml_file = lambda path: _pb_cfg(pb) if os.path.basename(path) == "tiny.yaml" else orig_cfg(path)
+    cfg = PointLLMConfig(hidden_size=lm.hidden_size, intermediate_size=lm.intermediate_size,
+                         num_hidden_layers=lm.num_hidden_layers, num_attention_heads=lm.num_attention_heads,
+                         num_key_value_heads=lm.num_attention_heads, vocab_size=lm.vocab_size,
+                         rms_norm_eps=lm.rms_norm_eps, max_position_embeddings=lm.max_position_embeddings,
+                         pad_token_id=tok.pad, bos_token_id=tok.bos, eos_token_id=tok.eos,
+                         point_backbone="PointBERT", point_backbone_config_name="tiny", use_color=True,
+                         mm_use_point_start_end=True, DEFAULT_POINT_PATCH_TOKEN="<point_patch>",
+                         DEFAULT_POINT_START_TOKEN="<point_start>", DEFAULT_POINT_END_TOKEN="<point_end>",
+                         tie_word_embeddings=False, attn_implementation="eager")
+    base = PointLLMLlamaForCausalLM(cfg)
+    sd = synth.synth_state_dict(dims, 0)
+    base.load_state_dict(sd, strict=True)
+    tmp = tempfile.mkdtemp()
+    base.save_pretrained(tmp)
+    args = types.SimpleNamespace(unfreeze_pc_encoder=True, unfreeze_language_model=False, model_name=tmp, num_bins=tok.num_bins)
+    model = RMA.TrajPointLLMForCausalLM(args, cfg, tmp)
+    model.load_state_dict(sd, strict=True)
+    model.get_model().point_backbone_config.update(point_patch_token=tok.point_patch, point_start_token=tok.point_start, point_end_token=tok.point_end)
+    rates = [float(getattr(b.drop_path, "drop_prob", 0.0)) for b in model.model.point_backbone.blocks.blocks]     # p = 0 -> nn.Identity (point_encoder.py:65)
+    assert rates == [0.0, 0.5], rates
+    B = 4
+    toks, masks, Lp = synth.synth_batch(dims, B, text_len=8, num_steps=4, max_traj_token=40)
+    pts = torch.stack([synth.synth_cloud(dims, i) for i in range(B)])
+    start = np.array([0, 17, 3, 9])
+    draws = [torch.tensor([1.0, 0.0, 1.0, 1.0]), torch.tensor([0.0, 1.0, 1.0, 0.0])]       # block 1: attention branch, MLP branch
+    model.train()
+    TL.MASKS, TL.USED[:] = [d.clone() for d in draws], []
+    try:
+        with fixed_fps_start(start):
+            o = model(input_ids=toks, attention_mask=masks, point_clouds=pts, return_dict=True)
+    finally:
+        left, TL.MASKS = TL.MASKS, None
+    assert left == [] and [p_ for p_, _ in TL.USED] == [0.5, 0.5]                         # both draws consumed, by the p = 0.5 block
+    lg = o.logits[:, Lp - 1:-1, :]
+    loss = F.cross_entropy(lg.reshape(-1, lg.shape[-1]), toks[:, Lp:].flatten(), ignore_index=tok.pad)
+    loss.backward()
+    grads = {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+    scales = torch.ones(pb.depth, 2, B)
+    scales[1, 0], scales[1, 1] = draws[0] / 0.5, draws[1] / 0.5
+    sd_o = {k: v.clone().requires_grad_(v.dtype.is_floating_point and not k.startswith("model.layers.") and k.rsplit(".", 1)[-1] not in ("running_mean", "running_var"))
+            for k, v in sd.items()}
+    lo = OPL.forward(sd_o, dims, toks, masks, pts, start, pc_train=True, pc_drop=scales)
+    loss_o = OL.traj_loss(lo, toks, Lp, tok.pad)
+    loss_o.backward()
+    worst = max(rel(sd_o[n].grad, g) for n, g in grads.items() if float(g.abs().max()) > 1e-6)      # (conv biases in front of a train-mode BatchNorm: exact gradient 0)
+    print("tiny_pc_unfrozen_droppath: loss", float(loss), float(loss_o), " logits rel", rel(lo.detach(), o.logits.detach()), " worst grad rel", worst)
+    assert abs(float(loss) - float(loss_o)) < 1e-5 * abs(float(loss)) and worst < 1e-4
+    # not vacuous: the same batch at rate 0 gives another loss
+    with torch.no_grad():
+        l0 = OL.traj_loss(OPL.forward(sd, dims, toks, masks, pts, start, pc_train=True), toks, Lp, tok.pad)
+    assert abs(float(l0) - float(loss)) > 1e-4 * abs(float(loss)), (float(l0), float(loss))
+    out = {"loss": np.array(float(loss)), "loss_rate0": np.array(float(l0)), "logits": o.logits.detach().numpy(), "fps_start": start,
+           "drop_scales": scales.numpy(), "drop_path_rate": np.array(0.5), "grad_names_all": np.array(sorted(grads))}
+    for n in ("cls_token", "encoder.first_conv.0.weight", "encoder.second_conv.3.weight", "reduce_dim.weight", "pos_embed.2.weight",
+              "blocks.blocks.0.attn.qkv.weight", "blocks.blocks.0.mlp.fc2.bias", "blocks.blocks.1.norm1.weight", "blocks.blocks.1.attn.qkv.weight",
+              "blocks.blocks.1.attn.proj.bias", "blocks.blocks.1.norm2.bias", "blocks.blocks.1.mlp.fc1.weight", "blocks.blocks.1.mlp.fc2.bias", "norm.weight"):
+        out["grad:model.point_backbone." + n] = grads["model.point_backbone." + n].numpy()
+    out["grad:model.point_proj.0.weight"] = grads["model.point_proj.0.weight"].numpy()
+    np.savez_compressed(os.path.join(GOLD, "tiny_pc_unfrozen_droppath.npz"), **out)
+    RPL.cfg_from_yaml_file = orig_cfg
+
+
 def gen_tiny_model_bf16():
     """The reference's TRAINING numerics: bf16 weights (DeepSpeed `bf16: enabled`, train.py:97-98) under
     autocast(bfloat16) (train.py:166) — run here on the CPU (`torch.autocast("cpu", torch.bfloat16)`), same tiny model,
@@ -966,7 +1042,7 @@ def gen_multi_segment():
 
 if __name__ == "__main__":
     which = sys.argv[1:] or ["pointcloud", "depth_cloud", "traj", "collate", "pointbert_full", "tiny_model", "tiny_pc_unfrozen", "tiny_model_bf16", "tiny_trained",
-                             "sampling", "train_steps", "multi_segment", "traj_formats"]
+                             "sampling", "train_steps", "multi_segment", "traj_formats", "tiny_pc_unfrozen_droppath"]
     for w in which:
         globals()["gen_" + w]()
     sizes = {f: os.path.getsize(os.path.join(GOLD, f)) for f in sorted(os.listdir(GOLD))}

@@ -128,19 +128,22 @@ def vit_attention(sd, p, x, num_heads):
     return F.linear(y, sd[p + "proj.weight"], sd[p + "proj.bias"])
 
 
-def vit_block(sd, p, x, num_heads, eps=1e-5):
+def vit_block(sd, p, x, num_heads, eps=1e-5, drop=None):
+    """drop: None, or [2, B] per-sample scales of the two residual branches (DropPath in train mode, point_encoder.py:65,74-75:
+    mask / keep_prob with mask = floor(keep_prob + U), timm 0.4.12)."""
     C = x.shape[-1]
     h = F.layer_norm(x, (C,), sd[p + "norm1.weight"], sd[p + "norm1.bias"], eps)
-    x = x + vit_attention(sd, p + "attn.", h, num_heads)                         # point_encoder.py:74
+    a = vit_attention(sd, p + "attn.", h, num_heads)
+    x = x + (a if drop is None else a * drop[0].to(a.dtype)[:, None, None])      # point_encoder.py:74
     h = F.layer_norm(x, (C,), sd[p + "norm2.weight"], sd[p + "norm2.bias"], eps)
     h = F.gelu(F.linear(h, sd[p + "mlp.fc1.weight"], sd[p + "mlp.fc1.bias"]))    # exact erf GELU
     h = F.linear(h, sd[p + "mlp.fc2.weight"], sd[p + "mlp.fc2.bias"])
-    return x + h                                                                 # point_encoder.py:75
+    return x + (h if drop is None else h * drop[1].to(h.dtype)[:, None, None])   # point_encoder.py:75
 
 
-def point_transformer_from_groups(sd, prefix, neighborhood, center, depth, num_heads, taps=None, training=False):
+def point_transformer_from_groups(sd, prefix, neighborhood, center, depth, num_heads, taps=None, training=False, drop=None):
     """Everything after grouping (point_encoder.py:173-186). neighborhood/center: torch f32.
-    training=True: BatchNorm in train mode; DropPath is taken at rate 0 (stochastic depth is not pinned)."""
+    training=True: BatchNorm in train mode; DropPath through `drop` [depth, 2, B] (per-sample branch scales, see vit_block; None = rate 0)."""
     tok = pointnet_encoder(sd, prefix + "encoder.", neighborhood, training=training)
     if taps is not None:
         taps["pointnet"] = tok
@@ -155,18 +158,18 @@ def point_transformer_from_groups(sd, prefix, neighborhood, center, depth, num_h
     if taps is not None:
         taps["x0"], taps["pos"] = x, pos
     for i in range(depth):
-        x = vit_block(sd, f"{prefix}blocks.blocks.{i}.", x + pos, num_heads)     # pos re-added: :95-98
+        x = vit_block(sd, f"{prefix}blocks.blocks.{i}.", x + pos, num_heads, drop=None if drop is None else drop[i])     # pos re-added: :95-98
         if taps is not None:
             taps[f"block{i}"] = x
     C = x.shape[-1]
     return F.layer_norm(x, (C,), sd[prefix + "norm.weight"], sd[prefix + "norm.bias"], 1e-5)
 
 
-def point_transformer(sd, prefix, pts: torch.Tensor, pb, start, taps=None, training=False):
+def point_transformer(sd, prefix, pts: torch.Tensor, pb, start, taps=None, training=False, drop=None):
     """pts [B,N,C] f32 -> [B,G+1,trans_dim] (use_max_pool=false: all tokens, point_encoder.py:186-187)."""
     nb, center, fidx, kidx = group(pts.detach().numpy(), pb.num_group, pb.group_size, np.asarray(start))
     if taps is not None:
         taps["fps_idx"], taps["knn_idx"] = fidx, kidx
         taps["neighborhood"], taps["center"] = nb, center
     return point_transformer_from_groups(sd, prefix, torch.from_numpy(nb), torch.from_numpy(center),
-                                         pb.depth, pb.num_heads, taps, training=training)
+                                         pb.depth, pb.num_heads, taps, training=training, drop=drop)

@@ -63,7 +63,7 @@ def splice(input_ids, inputs_embeds, point_features, tok, P):
     return torch.stack(rows, 0)
 
 
-def forward(sd, dims, input_ids, attention_mask, point_clouds, fps_start, kv_cache=None, taps=None, pc_train=False):
+def forward(sd, dims, input_ids, attention_mask, point_clouds, fps_start, kv_cache=None, taps=None, pc_train=False, pc_drop=None):
     """Whole model -> logits [B,S,V] (pointllm.py:90-178,215-228).  pc_train=False: frozen eval-mode point
     backbone (the default flags); True: --unfreeze_pc_encoder in train() (gradients flow into it, BatchNorm
     uses batch statistics and updates the running stats held in `sd`)."""
@@ -71,7 +71,7 @@ def forward(sd, dims, input_ids, attention_mask, point_clouds, fps_start, kv_cac
     emb = F.embedding(input_ids, sd["model.embed_tokens.weight"])
     if point_clouds is not None and (input_ids.shape[1] != 1):
         if pc_train:
-            feats = PB.point_transformer(sd, "model.point_backbone.", point_clouds, pb, fps_start, taps, training=True)
+            feats = PB.point_transformer(sd, "model.point_backbone.", point_clouds, pb, fps_start, taps, training=True, drop=pc_drop)
         else:
             with torch.no_grad():
                 feats = PB.point_transformer(sd, "model.point_backbone.", point_clouds, pb, fps_start, taps)

@@ -23,7 +23,10 @@ def golden_dir():
 def _release_cached_device_memory(request):
     """GPU box: hand the caching allocator's free blocks back to the driver after every test module.  The full-size modules reserve well over 100 GB
     each; what torch keeps cached is invisible to everything that allocates outside torch (RCCL, the runtime's scratch memory for kernels with
-    spills), and one full-suite run in round 3 ended in a silent runtime abort inside a later, small test."""
+    spills), so modules start from a clean pool.  (This fixture was added while chasing round 3's intermittent abort of the full suite; cached
+    memory was NOT its cause: `attn_bwd_dkdv2_kernel` read LSE / delta 128 B past the end of those arrays at S % 32 == 0 — commit 00c14e3,
+    DESIGN.md §5 — and faulted whenever such an array closed a mapped segment.  tests/test_gpu_bounds.py now places every operand of the
+    LDS-DMA kernels at the end of an allocation of its own, at aligned sizes too.)"""
     yield
     torch = sys.modules.get("torch")
     if torch is not None and torch.cuda.is_available() and torch.cuda.is_initialized():

@@ -609,10 +609,69 @@ def test_fused_attention_forward_second_form_is_bit_identical(ops, hd, B, S, H, 
             torch.cuda.synchronize()
             res[form] = (out, lse)
     finally:
-        L.egomi_attn_set_fwd_form(2)
+        L.egomi_attn_set_fwd_form(3)
     assert torch.equal(res[1][0], res[2][0])
     assert torch.equal(res[1][1], res[2][1])
     assert bool(torch.isfinite(res[2][0].float()).all())
+
+
+@pytest.mark.parametrize("group", [0, 3])
+@pytest.mark.parametrize("B,S,H,causal,mask", [(2, 692, 3, True, "tail"), (1, 692, 2, True, None), (2, 513, 2, False, None), (1, 200, 2, True, "holes"),
+                                               (2, 64, 1, False, "tail"), (1, 33, 2, True, None), (1, 1, 1, True, None), (2, 300, 2, False, "holes"),
+                                               (1, 1000, 1, True, "tail"), (8, 256, 4, True, "tail"), (1, 128, 1, True, None), (1, 32, 1, True, None),
+                                               (1, 31, 1, False, None), (3, 97, 2, True, "holes"), (1, 2048, 2, True, None)])
+def test_fused_attention_forward_third_form(ops, B, S, H, causal, mask, group):
+    """attn_fwd3_kernel (round 4, the default at head_dim 128: 32-key ring, scores of tile t+1 under the exponentials of tile t, LAZY running max,
+    query blocks aligned to the end of the sequence — rows q < 0 in the first block, dead waves, diagonal / ragged / padded tiles, both block
+    orders) against fp32 torch and against the second form: not the same bits (P is taken against a stale maximum, up to 2^6), the same
+    tolerance; LSE is exact either way."""
+    from egoscaler_amd import _lib
+    L = _lib.lib()
+    hd = 128
+    qkv = rnd(B * S, 3 * H * hd, dtype=torch.bfloat16, seed=S + 3)
+    km = None
+    if mask is not None:
+        km = torch.ones(B, S, dtype=torch.uint8)
+        if mask == "tail":
+            km[-1, S - max(1, S // 5):] = 0
+        else:
+            km[0, 2:4] = 0
+            km[-1, S // 2] = 0
+    ref, lse_ref = _ref_attention(qkv, B, S, H, hd, hd ** -0.5, causal, km)
+    kmc = None if km is None else km.cuda()
+    res = {}
+    try:
+        for form in (2, 3):
+            assert L.egomi_attn_set_fwd_form(form) == 0 and L.egomi_attn_set_fwd_group(group) == 0
+            out = torch.full((B * S, H * hd), 7.0, dtype=torch.bfloat16, device="cuda")
+            lse = torch.full((B, H, S), 7.0, dtype=torch.float32, device="cuda")
+            ops.attn_fwd(qkv.cuda(), B, S, H, hd, hd ** -0.5, out, lse, causal=causal, key_mask=kmc)
+            torch.cuda.synchronize()
+            res[form] = (out.float().cpu(), lse.cpu())
+    finally:
+        L.egomi_attn_set_fwd_form(3)
+        L.egomi_attn_set_fwd_group(0)
+    scale = float(ref.abs().max())
+    e2, e3 = float((res[2][0] - ref).abs().max()), float((res[3][0] - ref).abs().max())
+    assert e3 <= 2e-2 * scale and e3 <= max(2.0 * e2, 1e-2 * scale), (e2, e3, scale)
+    assert float((res[3][1] - lse_ref).abs().max()) < 2e-2 and bool(torch.isfinite(res[3][0]).all())
+
+
+def test_fused_attention_forward_third_form_rescales_on_a_late_maximum(ops):
+    """The lazy maximum's rare branch (cdna_hip_programming.md rule 26): one key far above every earlier score, placed in a late tile, forces
+    the rescale of O and l there; a key just UNDER the threshold (2^6 in the exp2 domain) must not.  Full-tensor fp32 reference."""
+    B, S, H, hd = 1, 320, 2, 128
+    qkv = rnd(B * S, 3 * H * hd, dtype=torch.bfloat16, seed=77).float() * 0.3
+    x = qkv.view(B, S, 3, H, hd)
+    x[0, 250, 1, 0] = x[0, 300, 0, 0] * 6.0                             # key 250 of head 0 lines up with query 300: a score far above the rest
+    x[0, 200, 1, 1] = x[0, 310, 0, 1] * 1.2                             # head 1: a mild outlier, under the threshold
+    qkv = qkv.bfloat16()
+    ref, lse_ref = _ref_attention(qkv, B, S, H, hd, hd ** -0.5, True, None)
+    out = torch.zeros(B * S, H * hd, dtype=torch.bfloat16, device="cuda")
+    lse = torch.zeros(B, H, S, dtype=torch.float32, device="cuda")
+    ops.attn_fwd(qkv.cuda(), B, S, H, hd, hd ** -0.5, out, lse, causal=True, key_mask=None)
+    close(out, ref, 2e-2)
+    assert float((lse.cpu() - lse_ref).abs().max()) < 2e-2
 
 
 @pytest.mark.parametrize("B,S,H,causal,masked", [(2, 513, 6, False, False), (1, 65, 2, False, True), (2, 200, 3, True, True), (1, 1, 1, False, False)])
@@ -703,7 +762,7 @@ def test_fused_attention_backward_second_form_is_bit_identical(ops, B, S, H, cau
         rp = (cos.cuda(), sin.cuda())
     res = {}
     try:
-        for form in (1, 2):
+        for form in (1, 2, 3):
             assert L.egomi_attn_set_bwd_form(form) == 0
             dqkv = torch.full((B * S, 3 * d), 3.0, dtype=torch.bfloat16, device="cuda")
             delta, _keep1 = at_end(B * H * S)
@@ -712,11 +771,12 @@ def test_fused_attention_backward_second_form_is_bit_identical(ops, B, S, H, cau
             torch.cuda.synchronize()
             res[form] = (dqkv, delta)
     finally:
-        L.egomi_attn_set_bwd_form(2)
-    assert torch.equal(res[1][1], res[2][1])
-    for i, nm in enumerate("qkv"):
-        assert torch.equal(res[1][0][:, i * d:(i + 1) * d], res[2][0][:, i * d:(i + 1) * d]), nm
-    assert bool(torch.isfinite(res[2][0].float()).all())
+        L.egomi_attn_set_bwd_form(3)
+    for f in (2, 3):                                                        # form 3 (round 4): the dQ kernel on the forward's 32-key ring, end-aligned query blocks
+        assert torch.equal(res[1][1], res[f][1]), f
+        for i, nm in enumerate("qkv"):
+            assert torch.equal(res[1][0][:, i * d:(i + 1) * d], res[f][0][:, i * d:(i + 1) * d]), (f, nm)
+        assert bool(torch.isfinite(res[f][0].float()).all())
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])

@@ -128,3 +128,54 @@ def test_bf16_point_backbone_training_on_fused_head_dim_64_attention():
         worst = max(worst, e_f)
         assert e_f <= max(2.0 * e_u, 5e-2), (n, e_f, e_u)                # as close to fp32 as the unfused bf16 path is
     assert worst > 0
+
+
+def test_unfrozen_point_backbone_with_droppath_matches_reference(golden_dir):
+    """Stochastic depth ON (point_encoder.py:65,74-75,133-134): the reference's run took its per-sample DropPath draws from
+    the fixture generator (oracle/_shims/timm: timm 0.4.12's x / keep * floor(keep + U) with U handed in; depth 2 at rate 0.5 -> block 1 drops
+    at p = 0.5, block 0 is an Identity), the product receives the same draws as branch scales [depth, 2, B].  Loss, logits-derived loss and
+    the point-backbone gradients <= 1e-3; the rate-0 loss of the same batch differs (the draws matter)."""
+    g = np.load(os.path.join(golden_dir, "tiny_pc_unfrozen_droppath.npz"), allow_pickle=False)
+    dims = dims_tiny()
+    dims.pb.drop_path_rate = float(g["drop_path_rate"])
+    B = 4
+    toks, masks, Lp = synth.synth_batch(dims, B, text_len=8, num_steps=4, max_traj_token=40)
+    pts = torch.stack([synth.synth_cloud(dims, i) for i in range(B)])
+    m = _model(dims)
+    m.train()
+    scales = torch.from_numpy(g["drop_scales"]).to(torch.float32)
+    assert scales.shape == (dims.pb.depth, 2, B) and float(scales[0].min()) == 1.0 and sorted(set(scales[1].flatten().tolist())) == [0.0, 2.0]
+    m.engine.pb_drop_override = scales.cuda().contiguous()
+    loss = m.loss_and_backward(toks.cuda(), masks.cuda(), pts.cuda(), Lp, dims.tok.pad, fps_start=g["fps_start"])
+    assert m.engine.pb_drop_override is None                              # consumed by that pass
+    assert abs(float(loss) - float(g["loss"])) < REL * abs(float(g["loss"]))
+    assert abs(float(g["loss_rate0"]) - float(g["loss"])) > 1e-4 * abs(float(g["loss"]))
+    params = dict(m.named_parameters())
+    got = sorted(n for n, p in params.items() if getattr(p, "main_grad", None) is not None)
+    assert got == g["grad_names_all"].tolist()
+    for k in g.files:
+        if k.startswith("grad:"):
+            assert rel(params[k[5:]].main_grad, g[k]) < REL, (k, rel(params[k[5:]].main_grad, g[k]))
+
+
+def test_point_backbone_with_96_wide_heads_matches_oracle():
+    """The second PointBERT YAML the reference ships (PointTransformer_base_8192point.yaml: trans_dim 1152 = 12 heads x 96, no projection hidden
+    layers; accepted by PointLLMConfig.POINTBERT_BY_NAME) at tiny size: head_dim 96 has no fused attention kernel (engine.py fuses 64 and 128),
+    so the blocks take the generic batched-GEMM + softmax path — pinned here against the oracle's run of the same geometry."""
+    from egoscaler_amd.pointllm import TrajPointLLMForCausalLM
+    from oracle import pointllm as OPL
+    dims = dims_tiny()
+    dims.pb.trans_dim, dims.pb.num_heads = 192, 2                          # head_dim 96
+    dims.pb.projection_hidden_dim = []                                     # projection_hidden_layer: 0 -> one Linear (pointllm.py:78-81)
+    assert dims.pb.head_dim == 96
+    args = types.SimpleNamespace(unfreeze_pc_encoder=False, unfreeze_language_model=False, num_bins=dims.tok.num_bins, model_name=None)
+    m = TrajPointLLMForCausalLM(args, dims, None, device="cuda", dtype=torch.float32).eval()
+    sd = synth.synth_state_dict(dims, 0)
+    assert sd["model.point_backbone.blocks.blocks.0.attn.qkv.weight"].shape == (576, 192) and "model.point_proj.2.weight" not in sd
+    m.load_state_dict(sd)
+    toks, masks, Lp = synth.synth_batch(dims, 2, text_len=8, num_steps=4, max_traj_token=40)
+    pts = torch.stack([synth.synth_cloud(dims, i) for i in range(2)])
+    with torch.no_grad():
+        lg = m(input_ids=toks.cuda(), attention_mask=masks.cuda(), point_clouds=pts.cuda(), fps_start=[0, 17]).logits
+        ref = OPL.forward({k: v.clone() for k, v in sd.items()}, dims, toks, masks, pts, np.array([0, 17]))
+    assert rel(lg, ref.numpy()) < REL

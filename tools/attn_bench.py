@@ -45,7 +45,7 @@ for rnd in range(3):                                       # the forms of the fo
         tf = timeit(lambda: ops.attn_fwd(qkv, B, S, H, hd, scale, out, lse, causal=True, key_mask=mask))
         print(f"B={B} S={S}: fwd form {form} group {grp}: {tf*1e3:7.1f} us {f/tf/1e9:7.1f} TFLOP/s", flush=True)
 _lib.lib().egomi_attn_set_fwd_form(3)
-for form in (1, 2, 1, 2):
+for form in (2, 3, 2, 3, 2, 3):
     _lib.lib().egomi_attn_set_bwd_form(form)
     tb = timeit(lambda: ops.attn_bwd(qkv, out, lse, dout, dqkv, delta, B, S, H, hd, scale, causal=True, key_mask=mask))
     print(f"B={B} S={S}: bwd form {form}: {tb*1e3:7.1f} us {2.5*f/tb/1e9:7.1f} TFLOP/s")
