@@ -748,6 +748,18 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(AttnArgs a) {
 //     instead of the last (S = 692: 36 instead of 41 64-key tile-steps per (b, h) pair, and no block runs 11 tiles with half its waves dead);
 //   * the row sum is kept per lane (each half-wave sums its own keys) and combined once at the end.
 // =================================================================================================
+// max of a value with its partner lane (l <-> l ^ 32): v_permlane32_swap needs no lane-index register (a __shfl_xor keeps one alive across the
+// whole tile loop and goes through the LDS crossbar)
+__device__ __forceinline__ float half_swap_max(float v) {
+    const uint32_t u = __float_as_uint(v);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float half_swap_sum(float v) {
+    const uint32_t u = __float_as_uint(v);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
 #define F3_KT 32
 #define F3_NST 4
 #define F3_TB (F3_KT * 256)                                            // bytes of one 32-key K or V tile (head_dim 128)
@@ -756,25 +768,28 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(AttnArgs a) {
 
 // one pipelined step: exponentials of tile t (scores in x, reference max m_run) beside the scores of tile t+1 (-> xn), then P.V of tile t
 // beside the mask + row max of tile t+1; the reference max moves only in the rare branch at the end.  HAS_NEXT = false: the wave's last tile.
-template <bool MASKED_NEXT, bool HAS_NEXT>
-__device__ __forceinline__ void f3_step(const char* sKn, const char* sV, const bf16x8 (&qf)[8], f32x16& x, f32x16 (&o)[4],
+// masked_next (wave-uniform, runtime): tile t+1 has invisible keys for some lane (diagonal, ragged, padded).  One instantiation serves both
+// kinds of tile: with a fully visible and a masked copy of this body inside the persistent kernel's item loop the allocator spilled the Q
+// fragments (reloaded — behind vmcnt(0) — in every tile step); the branch sits behind the P.V MFMAs, which run on while the VALU takes it.
+template <bool HAS_NEXT>
+__device__ __forceinline__ void f3_step(const bool masked_next, const char* sKn, const char* sV, const bf16x8 (&qf)[8], f32x16& x, f32x16 (&o)[4],
                                         float& m_run, float& l_run, const float sc2, const uint32_t vis_next, const int lane, const int half) {
     const float nm = m_run == -INFINITY ? 0.f : -m_run;
     f32x16 xn;
-    bf16x8 kf[8];
+    bf16x8 kf[4];
     if (HAS_NEXT) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) xn[r] = 0.f;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) kf[i] = lds_row8(sKn, lane & 31, 2 * i + half);
+        for (int i = 0; i < 4; ++i) kf[i] = lds_row8(sKn, lane & 31, 2 * i + half);
     }
-    bf16x8 vf[8];
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) vf[dt] = lds_tr8(sV, 0, 32 * dt, lane);
     float lsum = 0.f;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        if (HAS_NEXT) xn = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[i], qf[i], xn, 0, 0, 0);
+        if (HAS_NEXT) {
+            xn = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[i & 3], qf[i], xn, 0, 0, 0);
+            if (i < 4) kf[i] = lds_row8(sKn, lane & 31, 2 * (i + 4) + half);      // second batch of K fragments into the registers just consumed
+        }
 #pragma unroll
         for (int r = 2 * i; r < 2 * i + 2; ++r) {
             const float p = fast_exp2(fmaf(x[r], sc2, nm));            // exp2(-inf) = 0 for masked keys
@@ -783,8 +798,9 @@ __device__ __forceinline__ void f3_step(const char* sKn, const char* sV, const b
         }
     }
     l_run += lsum;
+    bf16x8 vf[4];                                                      // V^T fragments of the tile's first 16 keys; the second 16 follow into the same registers
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt) vf[4 + dt] = lds_tr8(sV, 16, 32 * dt, lane);
+    for (int dt = 0; dt < 4; ++dt) vf[dt] = lds_tr8(sV, 0, 32 * dt, lane);
     float pv8[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) pv8[j] = x[j];
@@ -793,18 +809,21 @@ __device__ __forceinline__ void f3_step(const char* sKn, const char* sV, const b
     for (int j = 0; j < 8; ++j) pv8[j] = x[8 + j];
     const bf16x8 pb1 = pack8(pv8);
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[dt], pb0, o[dt], 0, 0, 0);
+    for (int dt = 0; dt < 4; ++dt) {
+        o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[dt], pb0, o[dt], 0, 0, 0);
+        vf[dt] = lds_tr8(sV, 16, 32 * dt, lane);
+    }
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[4 + dt], pb1, o[dt], 0, 0, 0);
+    for (int dt = 0; dt < 4; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[dt], pb1, o[dt], 0, 0, 0);
     if (HAS_NEXT) {
-        if (MASKED_NEXT) {
+        if (masked_next) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) xn[r] = (vis_next >> rowmap(r, 0)) & 1u ? xn[r] : -INFINITY;
         }
         float mloc = fmaxf(xn[0], xn[1]);
 #pragma unroll
         for (int r = 2; r < 16; r += 2) mloc = fmaxf(mloc, fmaxf(xn[r], xn[r + 1]));
-        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64)) * sc2;              // sc2 > 0: max commutes with the scale
+        mloc = half_swap_max(mloc) * sc2;                                // sc2 > 0: max commutes with the scale
         if (__any(mloc > m_run + F3_THR)) {                              // rare after the first tiles (always at the first one: m_run = -inf)
             const float m_new = fmaxf(m_run, mloc);
             const float alpha = m_run == -INFINITY ? 0.f : fast_exp2(m_run - m_new);
@@ -936,7 +955,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd3_kernel(AttnArgs a, const int
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+        STAMP(4)
         if (t + 3 < ntiles) request();
+        STAMP(6)
     };
     auto kbits = [&](int t) -> uint32_t { return (uint32_t)__ballot(sMask[t * F3_KT + (lane & 31)] != 0); };
     f32x16 x;
@@ -954,31 +975,21 @@ __global__ __launch_bounds__(256, 2) void attn_fwd3_kernel(AttnArgs a, const int
         float mloc = fmaxf(x[0], x[1]);
 #pragma unroll
         for (int r = 2; r < 16; r += 2) mloc = fmaxf(mloc, fmaxf(x[r], x[r + 1]));
-        m_run = fmaxf(mloc, __shfl_xor(mloc, 32, 64)) * sc2;
+        m_run = half_swap_max(mloc) * sc2;
     }
     STAMP(3)
     int t = 0;
-    bool carried = false;
-    uint32_t km = 0u;
-    for (; t < n_int - 1; ++t) {                                       // tile t+1 fully visible: no mask work at all
+    for (; t < n_live - 1; ++t) {                                      // tile t+1: fully visible (no mask work) or diagonal / ragged / padded
         top(t);
-        STAMP(4)
-        km = kbits(t + 1);
-        if (km != 0xFFFFFFFFu) { carried = true; break; }              // a padded key in tile t+1: continue on the masked path
-        f3_step<false, true>(smem + ((t + 1) & 3) * F3_STAGE, smem + (t & 3) * F3_STAGE + F3_TB, qf, x, o, m_run, l_run, sc2, 0u, lane, half);
-        STAMP(5)
-    }
-    for (; t < n_live - 1; ++t) {
-        if (!carried) { top(t); STAMP(4) km = kbits(t + 1); }
-        carried = false;
+        const uint32_t km = kbits(t + 1);
+        const bool masked = t + 1 >= n_int || km != 0xFFFFFFFFu;
         const uint32_t vn = visible_bits(km, half, (t + 1) * F3_KT, qi, a.causal);
-        f3_step<true, true>(smem + ((t + 1) & 3) * F3_STAGE, smem + (t & 3) * F3_STAGE + F3_TB, qf, x, o, m_run, l_run, sc2, vn, lane, half);
+        f3_step<true>(masked, smem + ((t + 1) & 3) * F3_STAGE, smem + (t & 3) * F3_STAGE + F3_TB, qf, x, o, m_run, l_run, sc2, vn, lane, half);
         STAMP(5)
     }
     if (n_live > 0) {                                                  // t == n_live - 1: the wave's last tile
         top(t);
-        STAMP(4)
-        f3_step<false, false>(smem, smem + (t & 3) * F3_STAGE + F3_TB, qf, x, o, m_run, l_run, sc2, 0u, lane, half);
+        f3_step<false>(false, smem, smem + (t & 3) * F3_STAGE + F3_TB, qf, x, o, m_run, l_run, sc2, 0u, lane, half);
         STAMP(5)
         ++t;
     }
@@ -993,6 +1004,277 @@ __global__ __launch_bounds__(256, 2) void attn_fwd3_kernel(AttnArgs a, const int
         a.lse[((long long)b * a.H + h) * a.S + qi] = (m_run == -INFINITY) ? INFINITY : m_run * 0.6931471805599453f + logf(l_tot);
     STAMP(7)
     STAMP_FLUSH
+}
+
+
+// =================================================================================================
+// forward, fourth form (round 4; the default at head_dim 128): attn_fwd3_kernel made PERSISTENT.  What the third form's stamps and counters
+// said (profiles/README.md, round 4): 37 % of a block's life is its prologue (first K/V tiles, Q fragments, mask) and 15 % its epilogue, and
+// the kernel is NOT bound by traffic — with a (b, h) pair's blocks grouped on one XCD the fetch from beyond L2 falls to the algorithmic 133 MB
+// and the launch gets slower (schedule tail).  So the fixed cost per block is what to remove: here 2 x 256 blocks stay resident and walk the
+// work items (rank-major: longest causal ranges first; block i takes items i, i + grid, ...) as ONE continuous stream:
+//   * the K/V ring never drains: the request that follows an item's last tile is the next item's tile 0 (its tiles 0..2 are in LDS or in
+//     flight while the current item still computes);
+//   * a wave loads the next item's Q fragments into the registers of the current ones as soon as its last score tile is issued (they land
+//     under the last exponentials / P.V, the epilogue and the later waves' tiles);
+//   * the next item's key-mask bytes are fetched at the start of the current item and committed to the other of two LDS mask buffers;
+//   * O leaves through a wave-private strip that is NOT part of the ring (4 passes of 32 columns, 2.5 KB per wave), so the stores of item n
+//     overlap the first tiles of item n+1.
+// Arithmetic per item is attn_fwd3_kernel's (f3_step): the same bits.
+// =================================================================================================
+#define F4_SPITCH 80                                                   // strip row: 32 columns (64 B) + 16 B pad
+#define F4_STRIP (32 * F4_SPITCH)
+
+// O^T accumulators -> global rows, 32 columns per pass through the wave's strip
+__device__ __forceinline__ void f4_store_rows(char* wbuf, const f32x16 (&acc)[4], const float mul, bf16_t* gbase, const long long ld,
+                                              const int row0, const int nrows, const int lane) {
+    const int half = lane >> 5, rl = lane & 31;
+    const int r = lane >> 1, c0 = (lane & 1) * 2;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            u32x2 w;
+            w[0] = (uint32_t)f2bf(acc[dt][4 * g] * mul) | ((uint32_t)f2bf(acc[dt][4 * g + 1] * mul) << 16);
+            w[1] = (uint32_t)f2bf(acc[dt][4 * g + 2] * mul) | ((uint32_t)f2bf(acc[dt][4 * g + 3] * mul) << 16);
+            *reinterpret_cast<u32x2*>(wbuf + rl * F4_SPITCH + (8 * g + 4 * half) * 2) = w;
+        }
+        const u32x4 v0 = *reinterpret_cast<const u32x4*>(wbuf + r * F4_SPITCH + c0 * 16);
+        const u32x4 v1 = *reinterpret_cast<const u32x4*>(wbuf + r * F4_SPITCH + (c0 + 1) * 16);
+        if (row0 + r < nrows && row0 + r >= 0) {
+            bf16_t* dst = gbase + (long long)(row0 + r) * ld + 32 * dt + c0 * 8;
+            *reinterpret_cast<u32x4*>(dst) = v0;
+            *reinterpret_cast<u32x4*>(dst + 8) = v1;
+        }
+        __builtin_amdgcn_sched_barrier(0);                             // one pass at a time: scheduled together, the four passes' packed and read-back
+    }                                                                  // registers pushed the next item's prefetched Q fragments into scratch
+}
+
+// key-mask bytes of one sample for the persistent kernel (S <= 1024): four UNCONDITIONAL byte loads per thread (index clamped), committed later;
+// the branch around them is block-uniform.  (mask_fetch's per-element conditions made hipcc branch and wait vmcnt(0) per load once the
+// loads sat inside the item loop: cdna_hip_programming.md §5 ".s-level traps" (c).)
+__device__ __forceinline__ void f4_mask_fetch(const uint8_t* row, const int S, uint8_t (&mv)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int j = threadIdx.x + 256 * i;
+        j = j < S ? j : S - 1;
+        mv[i] = row[j];
+    }
+}
+__device__ __forceinline__ void f4_mask_commit(const bool have, const int S, const int S32, const uint8_t (&mv)[4], char* sMask) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int j = threadIdx.x + 256 * i;
+        if (j < S32) sMask[j] = j < S && (!have || mv[i] != 0);
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void attn_fwd4_kernel(AttnArgs a, const int n_items) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];       // [4 stages][K 8 KB | V 8 KB] | 4 strips | 2 key-mask buffers
+    const int lane = threadIdx.x & 63, half = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int S32 = (a.S + 31) & ~31;
+    char* strip = smem + F3_NST * F3_STAGE + wave * F4_STRIP;
+    char* sMaskBase = smem + F3_NST * F3_STAGE + 4 * F4_STRIP;
+    const int pairs = a.H * a.B;
+    const int nkt = (a.S + F3_KT - 1) / F3_KT;
+    const float sc2 = a.scale * 1.4426950408889634f;
+    const uint32_t tile_stride = (uint32_t)(F3_KT * a.ld_qkv * 2);
+    const uint32_t lds0 = (uint32_t)(uintptr_t)((lds_void_t*)smem) + wave * 2 * 1024;
+
+    // item -> (rank, b, h): rank-major, every pair's longest block first
+    auto decode = [&](int it, int& rank, int& b, int& h) {
+        rank = it / pairs;
+        const int pair = it - rank * pairs;
+        b = pair / a.H; h = pair - b * a.H;
+        rank = __builtin_amdgcn_readfirstlane(rank); b = __builtin_amdgcn_readfirstlane(b); h = __builtin_amdgcn_readfirstlane(h);
+    };
+    auto item_tiles = [&](int rank) -> int {
+        const int q0 = S32 - 128 * (rank + 1);
+        const int last = q0 + 127 < a.S - 1 ? q0 + 127 : a.S - 1;
+        return a.causal ? last / F3_KT + 1 : nkt;
+    };
+
+    // ---- request side: one continuous stream of K/V tiles over this block's items
+    int rq_it = blockIdx.x, rq_tile = 0, rq_ntiles = 0, g_issued = 0;
+    const bf16_t* Kq = a.k; const bf16_t* Vq = a.v;
+    uint32_t koff[2];
+    auto rq_open = [&]() {                                             // first tile of item rq_it
+        int rank, b, h;
+        decode(rq_it, rank, b, h);
+        rq_ntiles = item_tiles(rank);
+        rq_tile = 0;
+        const long long base = (long long)b * a.S * a.ld_qkv + h * AT_HD;
+        Kq = a.k + base; Vq = a.v + base;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int rl = (wave * 2 + j) * 4 + (lane >> 4);
+            const int ch = (lane & 15) ^ (((rl & 3) << 2) | ((rl >> 2) & 3));
+            const int r = rl < a.S ? rl : a.S - 1;
+            koff[j] = (uint32_t)((long long)r * a.ld_qkv + ch * 8) * 2u;
+        }
+    };
+    auto request = [&]() {                                             // next tile of the stream -> stage g_issued % 4 (caller: stream not exhausted)
+        const uint32_t base = __builtin_amdgcn_readfirstlane(lds0 + (g_issued & (F3_NST - 1)) * F3_STAGE);
+        if ((rq_tile + 1) * F3_KT <= a.S) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) dma16_asm(Kq, koff[j], base + j * 1024);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) dma16_asm(Vq, koff[j], base + F3_TB + j * 1024);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) koff[j] += tile_stride;
+        } else {                                                       // the sequence's ragged last tile: rows clamped to S - 1
+            uint32_t off[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int rl = (wave * 2 + j) * 4 + (lane >> 4);
+                const int ch = (lane & 15) ^ (((rl & 3) << 2) | ((rl >> 2) & 3));
+                int r = rq_tile * F3_KT + rl;
+                r = r < a.S ? r : a.S - 1;
+                off[j] = (uint32_t)((long long)r * a.ld_qkv + ch * 8) * 2u;
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) dma16_asm(Kq, off[j], base + j * 1024);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) dma16_asm(Vq, off[j], base + F3_TB + j * 1024);
+        }
+        ++g_issued;
+        if (++rq_tile == rq_ntiles) {                                  // the stream moves on to the block's next item
+            rq_it += gridDim.x;
+            if (rq_it < n_items) rq_open();
+        }
+    };
+    // top of stream tile g: tile g+1 (if requested) has landed for everybody, the stage of tile g-1 is free: keep three tiles requested ahead
+    int g = 0;
+    auto top = [&]() {
+        if (g_issued >= g + 3) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (rq_it < n_items && g_issued < g + 4) request();
+        ++g;
+    };
+
+    // ---- first item: the ordinary prologue
+    int it = blockIdx.x;
+    if (it >= n_items) return;
+    rq_open();
+    request();
+    if (rq_it < n_items) request();
+    int rank, b, h;
+    decode(it, rank, b, h);
+    bf16x8 qf[8];
+    {
+        const int q0 = S32 - 128 * (rank + 1);
+        const int qi = q0 + wave * 32 + (lane & 31);
+        const int qr = qi < 0 ? 0 : (qi < a.S ? qi : a.S - 1);
+        const bf16_t* Q = a.q + ((long long)b * a.S + qr) * a.ld_qkv + h * AT_HD;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(Q + 16 * ks + 8 * half);
+        uint8_t mv[4] = {1, 1, 1, 1};
+        if (a.key_mask) f4_mask_fetch(a.key_mask + (long long)b * a.S, a.S, mv);
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) asm volatile("" :: "v"(qf[ks]));
+        f4_mask_commit(a.key_mask != nullptr, a.S, S32, mv, sMaskBase);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (rq_it < n_items) request();                                // a third tile stays in flight across the barrier
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+    int parity = 0;
+    const int lane_entry = lane, half_entry = half;
+    for (;;) {
+        // ---- this item.  The lane index is made opaque per item: everything derived from it (the swizzled LDS read offsets of every
+        // instantiation of f3_step below) would otherwise be hoisted out of the item loop and live — spilled — across all of it
+        // (cdna_hip_programming.md, persistent-attention pitfalls: recompute lane-constant addresses per block)
+        int lane = lane_entry;
+        asm volatile("" : "+v"(lane));
+        const int half = lane >> 5;
+        (void)half_entry;
+        const int q0 = S32 - 128 * (rank + 1);
+        const long long row_base = (long long)b * a.S;
+        const int wave_q0 = q0 + wave * 32;
+        const int qi = wave_q0 + (lane & 31);
+        const int ntiles = item_tiles(rank);
+        const char* sMask = sMaskBase + parity * S32;
+        const int wl = wave_q0 + 31 < a.S - 1 ? wave_q0 + 31 : a.S - 1;
+        const int wf = wave_q0 < 0 ? 0 : wave_q0;
+        int n_live = wl < 0 ? 0 : (a.causal ? wl / F3_KT + 1 : ntiles);
+        n_live = n_live < ntiles ? n_live : ntiles;
+        int n_int = a.causal ? (wf >= F3_KT - 1 ? (wf - (F3_KT - 1)) / F3_KT + 1 : 0) : ntiles;
+        n_int = n_int < n_live ? n_int : n_live;
+        if (a.S % F3_KT && n_int == nkt) n_int = nkt - 1;
+        const int g0 = g;                                              // stream index of this item's tile 0
+        // ---- the next item of this block: its Q fragments and key-mask bytes are requested when this wave's last score tile has been issued
+        // (qf is dead from there on), they land under the last exponentials / P.V and the later waves' tiles
+        const int it_n = it + gridDim.x;
+        const bool has_next = it_n < n_items;
+        int rank_n = 0, b_n = 0, h_n = 0;
+        uint8_t mvn[4] = {1, 1, 1, 1};
+        auto prefetch_next = [&]() {
+            if (has_next) {
+                decode(it_n, rank_n, b_n, h_n);
+                const int qn = S32 - 128 * (rank_n + 1) + wave * 32 + (lane & 31);
+                const int qrn = qn < 0 ? 0 : (qn < a.S ? qn : a.S - 1);
+                const bf16_t* Qn = a.q + ((long long)b_n * a.S + qrn) * a.ld_qkv + h_n * AT_HD;
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(Qn + 16 * ks + 8 * half);
+                if (a.key_mask) f4_mask_fetch(a.key_mask + (long long)b_n * a.S, a.S, mvn);
+            }
+        };
+        auto kbits = [&](int t) -> uint32_t { return (uint32_t)__ballot(sMask[t * F3_KT + (lane & 31)] != 0); };
+
+        f32x16 o[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+        float m_run = -INFINITY, l_run = 0.f;
+        f32x16 x;
+        if (n_live > 0) {                                              // scores and reference max of tile 0 (in LDS: the previous top() saw to it)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) x[r] = 0.f;
+            const char* sK0 = smem + (g0 & 3) * F3_STAGE;
+            bf16x8 kf[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) kf[i] = lds_row8(sK0, lane & 31, 2 * i + half);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) x = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[i], qf[i], x, 0, 0, 0);
+            const uint32_t v0 = visible_bits(kbits(0), half, 0, qi, a.causal);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) x[r] = (v0 >> rowmap(r, 0)) & 1u ? x[r] : -INFINITY;
+            float mloc = fmaxf(x[0], x[1]);
+#pragma unroll
+            for (int r = 2; r < 16; r += 2) mloc = fmaxf(mloc, fmaxf(x[r], x[r + 1]));
+            m_run = half_swap_max(mloc) * sc2;
+        }
+        int t = 0;
+        for (; t < n_live - 1; ++t) {
+            top();
+            const uint32_t km = kbits(t + 1);
+            const bool masked = t + 1 >= n_int || km != 0xFFFFFFFFu;
+            const uint32_t vn = visible_bits(km, half, (t + 1) * F3_KT, qi, a.causal);
+            f3_step<true>(masked, smem + ((g0 + t + 1) & 3) * F3_STAGE, smem + ((g0 + t) & 3) * F3_STAGE + F3_TB, qf, x, o, m_run, l_run, sc2, vn, lane, half);
+        }
+        prefetch_next();                                               // qf is dead: the wave's last score tile has been issued (or it has none)
+        if (n_live > 0) {
+            top();
+            f3_step<false>(false, smem, smem + ((g0 + t) & 3) * F3_STAGE + F3_TB, qf, x, o, m_run, l_run, sc2, 0u, lane, half);
+            ++t;
+        }
+        for (; t < ntiles; ++t) top();                                 // tiles of the block's later waves: DMA share and barriers
+        if (has_next) f4_mask_commit(a.key_mask != nullptr, a.S, S32, mvn, sMaskBase + (parity ^ 1) * S32);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                                  // the next item's mask bytes are visible; every wave is done with this item's
+        const float l_tot = half_swap_sum(l_run);
+        const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+        f4_store_rows(strip, o, inv, a.o + row_base * a.ld_o + h * AT_HD, a.ld_o, wave_q0, a.S, lane);
+        if (qi >= 0 && qi < a.S && half == 0 && a.lse)
+            a.lse[((long long)b * a.H + h) * a.S + qi] = (m_run == -INFINITY) ? INFINITY : m_run * 0.6931471805599453f + logf(l_tot);
+        if (!has_next) break;
+        it = it_n; rank = rank_n; b = b_n; h = h_n;
+        parity ^= 1;
+    }
 }
 
 
@@ -1394,8 +1676,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq3_kernel(AttnArgs a) {
         }
         ++next_req;
     };
+    STAMP_DECL
+    STAMP_START
     request();
     if (ntiles > 1) request();
+    STAMP(0)
     uint8_t mv[AT_MASK_IT];
     mask_fetch(a, row_base, ntiles * F3_KT, mv);
     bf16x8 qf[8], dof[8];
@@ -1422,6 +1707,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq3_kernel(AttnArgs a) {
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) asm volatile("" :: "v"(qf[ks]), "v"(dof[ks]));
     asm volatile("" :: "v"(lse2), "v"(dlt));
+    STAMP(1)
     mask_commit(a, row_base, ntiles * F3_KT, mv, sMask);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // tiles 0 and 1 (and the delta store) are done
     if (ntiles > 2) request();                                         // tile 2 stays in flight across the barrier
@@ -1441,6 +1727,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq3_kernel(AttnArgs a) {
 
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                                      // tiles 0, 1 and the mask bytes are in LDS for every wave
+    STAMP(2)
     // top of tile t: tile t has landed for everybody (tiles t+1, t+2 may still be in flight), stage (t+3) % 4 = tile t-1's is free: request tile t+3
     auto top = [&](int t) {
         if (t > 0) {
@@ -1459,23 +1746,29 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq3_kernel(AttnArgs a) {
     uint32_t km = 0u;
     for (; t < n_int; ++t) {
         top(t);
+        STAMP(4)
         km = kbits(t);
         if (km != 0xFFFFFFFFu) { carried = true; break; }
         const char* sK = smem + (t & 3) * F3_STAGE;
         dq2_subtile<false>(sK, sK + F3_TB, 0, qf, dof, dq, sc2, lse2, dlt, 0u, lane, half);
+        STAMP(5)
     }
     for (; t < n_live; ++t) {
-        if (!carried) { top(t); km = kbits(t); }
+        if (!carried) { top(t); STAMP(4) km = kbits(t); }
         carried = false;
         const char* sK = smem + (t & 3) * F3_STAGE;
         const uint32_t v0 = visible_bits(km, half, t * F3_KT, qi, a.causal);
         dq2_subtile<true>(sK, sK + F3_TB, 0, qf, dof, dq, sc2, lse2, dlt, v0, lane, half);
+        STAMP(5)
     }
     for (; t < ntiles; ++t) top(t);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                                      // nobody reads a stage any more: the ring becomes the epilogue's strips
+    STAMP(6)
     store_rows_via_lds(smem + wave * AT_XBYTES, dq, a.scale, a.dq + row_base * a.ld_dqkv + h * AT_HD, a.ld_dqkv, wave_q0, a.S, lane,
                        a.rope_cos, a.rope_sin);
+    STAMP(7)
+    STAMP_FLUSH
 }
 
 // =================================================================================================
@@ -1859,11 +2152,11 @@ static bool occ_dq2() { return attn_occ() & 1; }
 
 static int g_attn_fwd_form = -1;
 static int attn_fwd_form() {
-    if (g_attn_fwd_form < 0) { const char* e = getenv("EGOMI_ATTN_FWD"); g_attn_fwd_form = e ? atoi(e) : 3; }
+    if (g_attn_fwd_form < 0) { const char* e = getenv("EGOMI_ATTN_FWD"); g_attn_fwd_form = e ? atoi(e) : 4; }
     return g_attn_fwd_form;
 }
 extern "C" int egomi_attn_set_fwd_form(int form) {
-    if (form < 1 || form > 3) return EGOMI_E_BADARG;
+    if (form < 1 || form > 4) return EGOMI_E_BADARG;
     g_attn_fwd_form = form;
     return EGOMI_OK;
 }
@@ -1876,6 +2169,12 @@ static int attn_fwd_group() {
 extern "C" int egomi_attn_set_fwd_group(int group) {
     if (group < 0 || group > 64) return EGOMI_E_BADARG;
     g_attn_fwd_group = group;
+    return EGOMI_OK;
+}
+static int g_attn_fwd_blocks = 0;
+extern "C" int egomi_attn_set_fwd_blocks(int blocks) {                  // 0 = two per CU; > 0 caps the persistent forward's grid (tests)
+    if (blocks < 0) return EGOMI_E_BADARG;
+    g_attn_fwd_blocks = blocks;
     return EGOMI_OK;
 }
 static int g_attn_bwd_form = -1;
@@ -1920,6 +2219,19 @@ extern "C" int egomi_attn_fwd(const egomi_attn_desc* d, egomi_stream_t stream) {
     const size_t lds = 2 * 2 * 64 * 2 * (size_t)d->head_dim + (size_t)((d->S + 63) / 64) * 64;
     int form = attn_fwd_form();                                        // EGOMI_ATTN_FWD=1 / egomi_attn_set_fwd_form(1): the first form (A/B runs, equality tests)
     if ((long long)d->S * d->ld_qkv * 2 >= (1ll << 32)) form = 1;      // the second and third forms address K/V rows with 32-bit byte offsets
+    if (d->head_dim == 128 && form == 4 && d->S > 1024) form = 3;       // the persistent form keeps a sample's key-mask bytes in four registers per thread
+    if (d->head_dim == 128 && form == 4) {
+        const int s32 = (d->S + 31) & ~31, nblk = (s32 + 127) / 128;
+        const int n_items = nblk * d->H * d->B;
+        static int cus = 0;
+        if (!cus) { int dev = 0; hipDeviceProp_t pr; cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ? pr.multiProcessorCount : 256; }
+        int grid4 = n_items < 2 * cus ? n_items : 2 * cus;                 // two resident blocks per CU walk the items
+        if (g_attn_fwd_blocks > 0 && g_attn_fwd_blocks < grid4) grid4 = g_attn_fwd_blocks;     // tests: several items per block at small shapes
+        const size_t lds4 = (size_t)F3_NST * F3_STAGE + 4 * F4_STRIP + 2 * (size_t)s32;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd4_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4);
+        EGOMI_LAUNCH(attn_fwd4_kernel, dim3((unsigned)grid4), dim3(256), lds4, (hipStream_t)stream, a, n_items);
+        return egomi_launch_status();
+    }
     if (d->head_dim == 128 && form == 3) {
         const int s32 = (d->S + 31) & ~31, nblk = (s32 + 127) / 128;
         int group = (d->H * d->B) % 8 == 0 ? attn_fwd_group() : 0;

@@ -213,10 +213,13 @@ typedef struct egomi_attn_desc {
 int egomi_attn_fwd(const egomi_attn_desc* desc, egomi_stream_t stream);
 int egomi_attn_bwd(const egomi_attn_desc* desc, egomi_stream_t stream);
 /* A/B switch (like the EGOMI_* environment switches): 1 = the first form of the forward kernel, 2 = the round-3 instruction stream
- * (bit-identical to 1: tests/test_gpu_kernels.py), 3 = the round-4 restructure (default at head_dim 128: 32-key tiles in a 4-stage ring,
- * QK of tile t+1 under the exponentials of tile t, lazy running max, end-aligned query blocks; same tolerances vs fp32, not the same bits).
+ * (bit-identical to 1: tests/test_gpu_kernels.py), 3 = the round-4 restructure (32-key tiles in a 4-stage ring, QK of tile t+1 under the
+ * exponentials of tile t, lazy running max, end-aligned query blocks; same tolerances vs fp32, not the same bits as 1 / 2), 4 = form 3 in
+ * persistent blocks (default at head_dim 128 and S <= 1024: two resident blocks per CU walk the work items as one continuous K/V stream,
+ * the next item's Q fragments and key mask prefetched; bit-identical to 3).
  * Process-wide, not thread-safe: measurement and tests only. */
 int egomi_attn_set_fwd_form(int form);
+int egomi_attn_set_fwd_blocks(int blocks);  /* form 4: cap the number of persistent blocks (0 = two per CU): tests reach several items per block at small shapes */
 int egomi_attn_set_fwd_group(int group);   /* block order of form 3: 0 = rank-major, G = a (b,h) pair's blocks in groups of G ranks on one XCD */
 int egomi_attn_set_bwd_form(int form);   /* likewise for the two backward kernels */
 

@@ -609,7 +609,7 @@ def test_fused_attention_forward_second_form_is_bit_identical(ops, hd, B, S, H, 
             torch.cuda.synchronize()
             res[form] = (out, lse)
     finally:
-        L.egomi_attn_set_fwd_form(3)
+        L.egomi_attn_set_fwd_form(4)
     assert torch.equal(res[1][0], res[2][0])
     assert torch.equal(res[1][1], res[2][1])
     assert bool(torch.isfinite(res[2][0].float()).all())
@@ -621,10 +621,11 @@ def test_fused_attention_forward_second_form_is_bit_identical(ops, hd, B, S, H, 
                                                (1, 1000, 1, True, "tail"), (8, 256, 4, True, "tail"), (1, 128, 1, True, None), (1, 32, 1, True, None),
                                                (1, 31, 1, False, None), (3, 97, 2, True, "holes"), (1, 2048, 2, True, None)])
 def test_fused_attention_forward_third_form(ops, B, S, H, causal, mask, group):
-    """attn_fwd3_kernel (round 4, the default at head_dim 128: 32-key ring, scores of tile t+1 under the exponentials of tile t, LAZY running max,
-    query blocks aligned to the end of the sequence — rows q < 0 in the first block, dead waves, diagonal / ragged / padded tiles, both block
-    orders) against fp32 torch and against the second form: not the same bits (P is taken against a stale maximum, up to 2^6), the same
-    tolerance; LSE is exact either way."""
+    """attn_fwd3_kernel (round 4: 32-key ring, scores of tile t+1 under the exponentials of tile t, LAZY running max, query blocks aligned to the
+    end of the sequence — rows q < 0 in the first block, dead waves, diagonal / ragged / padded tiles, both block orders) and attn_fwd4_kernel
+    (the default at head_dim 128: the same arithmetic in PERSISTENT blocks that walk the work items as one continuous K/V stream, next item's Q
+    and key mask prefetched; S > 1024 falls back to the third form) against fp32 torch and against the second form: not the same bits as the
+    second form (P is taken against a stale maximum, up to 2^6), the same tolerance; LSE is exact either way; forms 3 and 4 agree bit for bit."""
     from egoscaler_amd import _lib
     L = _lib.lib()
     hd = 128
@@ -641,7 +642,7 @@ def test_fused_attention_forward_third_form(ops, B, S, H, causal, mask, group):
     kmc = None if km is None else km.cuda()
     res = {}
     try:
-        for form in (2, 3):
+        for form in (2, 3, 4):
             assert L.egomi_attn_set_fwd_form(form) == 0 and L.egomi_attn_set_fwd_group(group) == 0
             out = torch.full((B * S, H * hd), 7.0, dtype=torch.bfloat16, device="cuda")
             lse = torch.full((B, H, S), 7.0, dtype=torch.float32, device="cuda")
@@ -649,12 +650,50 @@ def test_fused_attention_forward_third_form(ops, B, S, H, causal, mask, group):
             torch.cuda.synchronize()
             res[form] = (out.float().cpu(), lse.cpu())
     finally:
-        L.egomi_attn_set_fwd_form(3)
+        L.egomi_attn_set_fwd_form(4)
         L.egomi_attn_set_fwd_group(0)
     scale = float(ref.abs().max())
     e2, e3 = float((res[2][0] - ref).abs().max()), float((res[3][0] - ref).abs().max())
     assert e3 <= 2e-2 * scale and e3 <= max(2.0 * e2, 1e-2 * scale), (e2, e3, scale)
     assert float((res[3][1] - lse_ref).abs().max()) < 2e-2 and bool(torch.isfinite(res[3][0]).all())
+    assert torch.equal(res[3][0], res[4][0]) and torch.equal(res[3][1], res[4][1])        # the persistent form: the same arithmetic per item
+
+
+@pytest.mark.parametrize("blocks", [1, 3, 7])
+@pytest.mark.parametrize("B,S,H,causal,mask", [(2, 692, 3, True, "tail"), (3, 200, 2, True, "holes"), (2, 300, 2, False, "holes"), (4, 33, 2, True, None),
+                                               (2, 64, 3, False, "tail"), (1, 1000, 2, True, "tail")])
+def test_fused_attention_forward_persistent_blocks_walk_several_items(ops, B, S, H, causal, mask, blocks):
+    """attn_fwd4_kernel with its grid capped to 1 / 3 / 7 blocks: every block walks SEVERAL work items (different ranks, heads and samples, so the
+    K/V stream crosses item boundaries, the Q prefetch and the two key-mask buffers are exercised, items of one and two tiles follow long ones)
+    — bit-identical to the third form, which runs one block per item."""
+    from egoscaler_amd import _lib
+    L = _lib.lib()
+    hd = 128
+    qkv = rnd(B * S, 3 * H * hd, dtype=torch.bfloat16, seed=S + 5).cuda()
+    km = None
+    if mask is not None:
+        km = torch.ones(B, S, dtype=torch.uint8)
+        if mask == "tail":
+            km[-1, S - max(1, S // 5):] = 0
+            km[0, S - 3:] = 0
+        else:
+            km[0, 2:4] = 0
+            km[-1, S // 2] = 0
+        km = km.cuda()
+    res = {}
+    try:
+        for form in (3, 4):
+            assert L.egomi_attn_set_fwd_form(form) == 0 and L.egomi_attn_set_fwd_blocks(blocks if form == 4 else 0) == 0
+            out = torch.full((B * S, H * hd), 7.0, dtype=torch.bfloat16, device="cuda")
+            lse = torch.full((B, H, S), 7.0, dtype=torch.float32, device="cuda")
+            ops.attn_fwd(qkv, B, S, H, hd, hd ** -0.5, out, lse, causal=causal, key_mask=km)
+            torch.cuda.synchronize()
+            res[form] = (out, lse)
+    finally:
+        L.egomi_attn_set_fwd_form(4)
+        L.egomi_attn_set_fwd_blocks(0)
+    assert torch.equal(res[3][0], res[4][0]) and torch.equal(res[3][1], res[4][1])
+    assert bool(torch.isfinite(res[4][0].float()).all())
 
 
 def test_fused_attention_forward_third_form_rescales_on_a_late_maximum(ops):

@@ -39,12 +39,12 @@ f = 4.0 * B * H * S * S * hd / 2
 from egoscaler_amd import _lib
 groups = [int(g) for g in os.environ.get("ATTN_GROUPS", "0").split(",")]
 for rnd in range(3):                                       # the forms of the forward kernel, alternated on this box
-    for form, grp in [(2, 0)] + [(3, g) for g in groups]:
+    for form, grp in [(2, 0)] + [(3, g) for g in groups] + [(4, 0)]:
         _lib.lib().egomi_attn_set_fwd_form(form)
         _lib.lib().egomi_attn_set_fwd_group(grp)
         tf = timeit(lambda: ops.attn_fwd(qkv, B, S, H, hd, scale, out, lse, causal=True, key_mask=mask))
         print(f"B={B} S={S}: fwd form {form} group {grp}: {tf*1e3:7.1f} us {f/tf/1e9:7.1f} TFLOP/s", flush=True)
-_lib.lib().egomi_attn_set_fwd_form(3)
+_lib.lib().egomi_attn_set_fwd_form(4)
 for form in (2, 3, 2, 3, 2, 3):
     _lib.lib().egomi_attn_set_bwd_form(form)
     tb = timeit(lambda: ops.attn_bwd(qkv, out, lse, dout, dqkv, delta, B, S, H, hd, scale, causal=True, key_mask=mask))

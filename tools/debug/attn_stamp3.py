@@ -29,20 +29,28 @@ out = torch.empty(M, d, device="cuda", dtype=torch.bfloat16)
 lse = torch.empty(B, H, S, device="cuda", dtype=torch.float32)
 mask = torch.ones(B, S, device="cuda", dtype=torch.uint8)
 L = _lib.lib()
+L.egomi_attn_set_fwd_form(3)                       # the stamps sit in attn_fwd3_kernel (attn_fwd4_kernel runs the same steps)
+BWD = "bwd" in sys.argv[1:]
+dout = (torch.randn(M, d, device="cuda") * 0.1).bfloat16()
+dqkv = torch.empty_like(qkv)
+delta = torch.empty_like(lse)
+ops.attn_fwd(qkv, B, S, H, hd, hd ** -0.5, out, lse, causal=True, key_mask=mask)
+run = (lambda: ops.attn_bwd(qkv, out, lse, dout, dqkv, delta, B, S, H, hd, hd ** -0.5, causal=True, key_mask=mask)) if BWD else \
+      (lambda: ops.attn_fwd(qkv, B, S, H, hd, hd ** -0.5, out, lse, causal=True, key_mask=mask))
 for _ in range(5):
-    ops.attn_fwd(qkv, B, S, H, hd, hd ** -0.5, out, lse, causal=True, key_mask=mask)
+    run()
 torch.cuda.synchronize()
 L.egomi_attn_stamp_reset()
 N = 10
 for _ in range(N):
-    ops.attn_fwd(qkv, B, S, H, hd, hd ** -0.5, out, lse, causal=True, key_mask=mask)
+    run()
 torch.cuda.synchronize()
 buf = (ctypes.c_ulonglong * 16)()
 L.egomi_attn_stamp_read(buf)
 names = ["entry: block map, offsets, DMA 0/1 issue", "Q + mask loads issued and landed", "mask commit, vmcnt(0), barrier", "QK(0) + max(0)",
-         "top: vmcnt + barrier + request", "steps", "dead-tile tops + final barrier", "epilogue"]
+         "top: vmcnt + barrier", "steps", "top: request (4 LDS-DMA) [fwd3] / dead tops [dq3]", "epilogue"]
 tot = sum(buf[i] for i in range(8))
 blocks = buf[8]
-print(f"wave {w}: blocks stamped {blocks}, cycles per block {tot / blocks:.0f}")
+print(f"{'attn_bwd_dq3_kernel' if BWD else 'attn_fwd3_kernel'} wave {w}: blocks stamped {blocks}, cycles per block {tot / blocks:.0f}")
 for i, n in enumerate(names):
     print(f"  {n:40s} {buf[i] / blocks:9.0f} cycles/block  {100.0 * buf[i] / tot:5.1f} %")
