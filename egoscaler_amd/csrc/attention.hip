@@ -750,6 +750,19 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(AttnArgs a) {
 // =================================================================================================
 // max of a value with its partner lane (l <-> l ^ 32): v_permlane32_swap needs no lane-index register (a __shfl_xor keeps one alive across the
 // whole tile loop and goes through the LDS crossbar)
+// max of three in ONE instruction: fmaxf on MFMA outputs makes hipcc canonicalise each operand first (v_max_f32 x, x, x: 16 extra VALU per 32-key
+// tile in the forward's row-max chain; MI355X_MICROARCH.md "canonicalising v_max").  The scores are never signalling NaNs, so the bare v_max3 is exact.
+__device__ __forceinline__ float max3_raw(float a, float b, float c) {
+    float d;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+__device__ __forceinline__ float row_max16(const f32x16& x) {
+    float m = max3_raw(x[0], x[1], x[2]);
+#pragma unroll
+    for (int r = 3; r < 15; r += 2) m = max3_raw(m, x[r], x[r + 1]);
+    return max3_raw(m, x[15], x[15]);
+}
 __device__ __forceinline__ float half_swap_max(float v) {
     const uint32_t u = __float_as_uint(v);
     const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
@@ -820,9 +833,7 @@ __device__ __forceinline__ void f3_step(const bool masked_next, const char* sKn,
 #pragma unroll
             for (int r = 0; r < 16; ++r) xn[r] = (vis_next >> rowmap(r, 0)) & 1u ? xn[r] : -INFINITY;
         }
-        float mloc = fmaxf(xn[0], xn[1]);
-#pragma unroll
-        for (int r = 2; r < 16; r += 2) mloc = fmaxf(mloc, fmaxf(xn[r], xn[r + 1]));
+        float mloc = row_max16(xn);
         mloc = half_swap_max(mloc) * sc2;                                // sc2 > 0: max commutes with the scale
         if (__any(mloc > m_run + F3_THR)) {                              // rare after the first tiles (always at the first one: m_run = -inf)
             const float m_new = fmaxf(m_run, mloc);
@@ -972,10 +983,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd3_kernel(AttnArgs a, const int
         const uint32_t v0 = visible_bits(kbits(0), half, 0, qi, a.causal);
 #pragma unroll
         for (int r = 0; r < 16; ++r) x[r] = (v0 >> rowmap(r, 0)) & 1u ? x[r] : -INFINITY;
-        float mloc = fmaxf(x[0], x[1]);
-#pragma unroll
-        for (int r = 2; r < 16; r += 2) mloc = fmaxf(mloc, fmaxf(x[r], x[r + 1]));
-        m_run = half_swap_max(mloc) * sc2;
+        m_run = half_swap_max(row_max16(x)) * sc2;
     }
     STAMP(3)
     int t = 0;
@@ -1243,10 +1251,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd4_kernel(AttnArgs a, const int
             const uint32_t v0 = visible_bits(kbits(0), half, 0, qi, a.causal);
 #pragma unroll
             for (int r = 0; r < 16; ++r) x[r] = (v0 >> rowmap(r, 0)) & 1u ? x[r] : -INFINITY;
-            float mloc = fmaxf(x[0], x[1]);
-#pragma unroll
-            for (int r = 2; r < 16; r += 2) mloc = fmaxf(mloc, fmaxf(x[r], x[r + 1]));
-            m_run = half_swap_max(mloc) * sc2;
+            m_run = half_swap_max(row_max16(x)) * sc2;
         }
         int t = 0;
         for (; t < n_live - 1; ++t) {
