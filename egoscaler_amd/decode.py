@@ -55,6 +55,13 @@ class Decoder:
         self.gu, self.act, self.x_out, self.hn, self.lg = z(B, 2 * Fd), z(B, Fd), z(B, d), z(B, d), z(B, V)
         self.tok = z(B, 1, dtype=torch.int64)
         self.gws = torch.empty(128 << 20, dtype=torch.uint8, device=dev)      # split-K slabs of the skinny decode GEMMs
+        # sequences, key mask, generator state and eos flags live in STATIC buffers, so that a captured token loop can be replayed by a later
+        # generate() call of the same geometry (run_validation: one capture per (prompt length, new tokens, sampling mode), not one per batch)
+        self.seq_buf = z(B, max_len, dtype=torch.int64)
+        self.mask_buf = torch.ones(B, max_len, dtype=torch.uint8, device=dev)
+        self.rng = z(2, dtype=torch.int64)
+        self.done_buf = z(B, dtype=torch.int32)
+        self._graphs, self._scores = {}, {}
         self.seq = None
         self.mask = None
         self.pos = 0
@@ -79,6 +86,18 @@ class Decoder:
             self.fused["down"] = ops.mm_slabs(self.act, w["model.layers.0.mlp.down_proj.weight"], self.x, self.gws, count_only=True)
 
     # -- prefill -------------------------------------------------------------------------------------
+    def _set_inputs(self, input_ids, mask, total_new):
+        """Prompt ids and key mask into the static buffers (`seq` is a [B, S0 + total_new] view of rows that are Smax long)."""
+        B, S0 = input_ids.shape
+        if S0 + total_new > self.Smax:
+            raise ValueError("prompt + new tokens exceed the decoder's cache length")
+        self.mask_buf.fill_(1)
+        self.mask_buf[:, :S0] = mask.to(torch.uint8)
+        self.mask = self.mask_buf
+        self.seq_buf.zero_()
+        self.seq_buf[:, :S0] = input_ids
+        self.seq = self.seq_buf[:, :S0 + total_new]
+
     def _sink(self, l, qkv, B, Sq):
         lm = self.eng.dims.lm
         H, hd, d = lm.num_attention_heads, lm.head_dim, lm.hidden_size
@@ -88,11 +107,9 @@ class Decoder:
         B, S0 = input_ids.shape
         dev = self.eng.device
         mask = torch.ones(B, S0, dtype=torch.bool, device=dev) if attention_mask is None else attention_mask.to(dev).bool()
-        self.mask = torch.cat([mask, torch.ones(B, self.Smax - S0, dtype=torch.bool, device=dev)], 1).to(torch.uint8).contiguous()
+        self._set_inputs(input_ids, mask, total_new)
         hn = self.eng.forward_hidden(input_ids, mask, point_clouds, fps_start, save=False, kv_sink=self._sink)
         self.pos = S0
-        self.seq = torch.zeros(B, S0 + total_new, dtype=torch.int64, device=dev)
-        self.seq[:, :S0] = input_ids
         last = hn.view(B, S0, -1)[:, -1].contiguous()
         ops.mm(last, self.eng.w["lm_head.weight"], out=self.lg)
         return self.lg
@@ -105,9 +122,7 @@ class Decoder:
         lm = eng.dims.lm
         H, hd, d = lm.num_attention_heads, lm.head_dim, lm.hidden_size
         mask = torch.ones(B, S0, dtype=torch.bool, device=dev) if attention_mask is None else attention_mask.to(dev).bool()
-        self.mask = torch.cat([mask, torch.ones(B, self.Smax - S0, dtype=torch.bool, device=dev)], 1).to(torch.uint8).contiguous()
-        self.seq = torch.zeros(B, S0 + total_new, dtype=torch.int64, device=dev)
-        self.seq[:, :S0] = input_ids
+        self._set_inputs(input_ids, mask, total_new)
         for b0 in range(0, B, chunk):
             b1 = min(B, b0 + chunk)
 
@@ -177,11 +192,14 @@ class Decoder:
         Returns (sequences [B, S0+T_new], processed scores fp32 [T_new, B, V]); rows that emitted `eos` continue with `pad`."""
         S0, dev = self.pos, self.eng.device
         V = self.lg.shape[1]
-        sc_buf = torch.empty(T_new, self.B, V, dtype=torch.float32, device=dev)
+        sc_buf = self._scores.get(T_new)
+        if sc_buf is None:
+            sc_buf = self._scores[T_new] = torch.empty(T_new, self.B, V, dtype=torch.float32, device=dev)
         if seed is None:
             seed = int(torch.randint(0, 2 ** 62, (1,)).item())            # the CPU default generator: torch.manual_seed() makes a run repeatable
-        self.rng = torch.tensor([int(seed), 0], dtype=torch.int64).to(dev)
-        self.done = torch.zeros(self.B, dtype=torch.int32, device=dev) if eos is not None else None
+        self.rng.copy_(torch.tensor([int(seed), 0], dtype=torch.int64))
+        self.done_buf.zero_()
+        self.done = self.done_buf if eos is not None else None
         kw = dict(repetition_penalty=float(repetition_penalty or 1.0), temperature=float(temperature or 1.0), top_k=int(top_k or 0),
                   top_p=float(1.0 if top_p is None else top_p), do_sample=bool(do_sample), rng=self.rng, eos=eos, pad=pad)
 
@@ -193,13 +211,19 @@ class Decoder:
         if not use_graph:
             steps()
         else:
-            g = torch.cuda.CUDAGraph()
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                with torch.cuda.graph(g, stream=side):
-                    steps()
-            torch.cuda.current_stream().wait_stream(side)
+            # the captured loop depends on the prompt length, the number of steps and the sampling parameters only (every buffer it touches is
+            # static, the seed and the eos flags are device memory): a later call with the same key replays it
+            key = (S0, T_new, kw["repetition_penalty"], kw["temperature"], kw["top_k"], kw["top_p"], kw["do_sample"], eos, pad)
+            g = self._graphs.get(key)
+            if g is None:
+                g = torch.cuda.CUDAGraph()
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    with torch.cuda.graph(g, stream=side):
+                        steps()
+                torch.cuda.current_stream().wait_stream(side)
+                self._graphs[key] = g
             g.replay()
             self.graph = g
         self.pos = S0 + T_new

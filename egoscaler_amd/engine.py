@@ -47,6 +47,7 @@ class Engine:
         self.dims, self.w, self.device, self.dtype = dims, params, device, dtype
         self.ws = Workspace(device)
         self.prepared = False
+        self.prepare_epoch = 0         # bumped by prepare(): holders of derived weight copies (decode.Decoder caches) key on it
         self.lm_wT, self.lm_wT_stale, self.lm_wT_ver = None, True, None     # padded transpose of lm_head for its dgrad (backward_logits)
         self.param_ref = {}                # name -> nn.Parameter (set by the model shell): in-place updates by torch optimizers bump ITS
                                            # _version, not that of the `.data` aliases held in self.w
@@ -212,6 +213,7 @@ class Engine:
         cos, sin = ops.rope_tables(lm.max_position_embeddings, lm.head_dim, lm.rope_theta)
         self.cos, self.sin = cos.to(self.device), sin.to(self.device)
         self.prepared = True
+        self.prepare_epoch += 1
 
     @staticmethod
     def _side_by_side(ts):

@@ -497,7 +497,19 @@ class TrajPointLLMForCausalLM(nn.Module):
                 raise ValueError(f"`{name}` has to be a strictly positive float, but is {v}")               # logits_process.py:239,307
         if top_p is not None and not (0 < float(top_p) <= 1.0):
             raise ValueError(f"`top_p` has to be a float > 0 and < 1, but is {top_p}")
-        dec = Decoder(eng, B, S0 + T)
+        # one Decoder (static KV cache + captured token loops) per geometry, kept while the decoder layers it holds stacked copies of cannot
+        # change: frozen-LLM mode, same prepared weights.  run_validation / evaluate (train.py:207-264, evaluate.py:104-154) call generate()
+        # once per batch: without this every batch re-allocated the cache and re-captured a graph of (new tokens x ~300) kernels
+        key = (B, S0 + T, eng.prepare_epoch)
+        cache = self.__dict__.setdefault("_decoders", {})
+        reuse = not eng.any_layer_trainable and os.environ.get("EGOMI_DECODER_CACHE", "1") != "0"
+        dec = cache.get(key) if reuse else None
+        if dec is None:
+            dec = Decoder(eng, B, S0 + T)
+            if reuse:
+                while len(cache) >= 2:                     # the full batch and the split's short last one; a cache is 2 * L * B * H * Smax * hd elements
+                    cache.pop(next(iter(cache)))
+                cache[key] = dec
         dec.prefill(ids, attention_mask, point_clouds, fps_start, T)
         if not do_sample:                                  # HF applies the warpers (temperature / top-k / top-p) in sampling mode only
             temperature, top_k, top_p = 1.0, 0, 1.0
@@ -508,7 +520,8 @@ class TrajPointLLMForCausalLM(nn.Module):
             hit = seq[:, S0:] == eos_token_id
             first = torch.where(hit.any(1), hit.int().argmax(1), torch.full((B,), T - 1, device=dev))
             stop = int(first.max()) + 1
-        return GenerateOutput(sequences=seq[:, :S0 + stop], scores=tuple(sc[t] for t in range(stop)))
+        sc = sc[:stop].clone()                              # the decoder's buffers are static (and the decoder may be reused by the next call):
+        return GenerateOutput(sequences=seq[:, :S0 + stop].clone(), scores=tuple(sc[t] for t in range(stop)))     # hand out copies
 
     def train(self, mode: bool = True):
         """model_arch.py:110-124: frozen parts stay in eval(); embed_tokens follows `mode`."""
