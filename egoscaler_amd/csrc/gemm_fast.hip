@@ -296,6 +296,93 @@ void gemm_nt_bf16_kernel(FastArgs g) {
 }
 
 // =================================================================================================
+// M <= 16: the projections of a cached decode step at the reference's own evaluation batch size (train.py:223-228 / evaluate.py:116-121 generate
+// for bs = 8; HF LlamaAttention / LlamaMLP forward, modeling_llama.py:243-281,174-176).  At eight rows a 128-row tile is 6 % full and its LDS
+// round trip is pure overhead (cdna_hip_programming.md §5 "GEMV / M <= 16": operands streamed once per block go straight to VGPRs), so this
+// kernel streams the weight rows from HBM into registers and multiplies them on the matrix cores with the activation rows as the OTHER operand:
+//   a block = 4 waves on the same 64 weight rows (4 accumulators of v_mfma_f32_16x16x32_bf16: D[n][m] = sum_k W[n][k] x[m][k]), the K range cut
+//   over gridDim.y slices x 4 waves in steps of 128 (4 MFMA K-steps); per load instruction the 4 lanes of a row read 64 contiguous bytes of it
+//   (the plain 16x16x32 operand map: a lane-contiguous variant, 64 B per LANE over four instructions, scattered every instruction over 64
+//   sectors and measured 15-30 % slower);
+//   the next step's 20 loads are in flight under the current 16 MFMAs; the 4 waves meet in LDS (fixed order) and the block writes either the
+//   finished rows (bias / activation / residual as egomi_gemm defines them) or its fp32 K-slice slab (EGOMI_EPI_SLABS or a planned split,
+//   summed by splitk_reduce_kernel / the decode step's slab consumers).
+// =================================================================================================
+#define GV_BN 64
+template <typename TC>
+__global__ __launch_bounds__(256) void gemv_m16_kernel(FastArgs g) {
+    __shared__ float red[4][GV_BN][17];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int n0 = blockIdx.x * GV_BN;
+    const int nl = lane & 15, grp = lane >> 4;
+    const int T = g.K / 128;
+    const int slot = blockIdx.y * 4 + wave, nslots = g.splitk * 4;
+    const int t0 = (int)((long long)T * slot / nslots), t1 = (int)((long long)T * (slot + 1) / nslots);
+    const int xm = nl < g.M ? nl : g.M - 1;
+    const bf16_t* xp = g.A + (long long)xm * g.lda + 8 * grp;
+    const bf16_t* wp[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        int r = n0 + 16 * j + nl;
+        r = r < g.N ? r : g.N - 1;
+        wp[j] = g.B + (long long)r * g.ldb + 8 * grp;
+    }
+    f32x4 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    bf16x8 xf[2][4], wf[2][4][4];
+    auto load = [&](int buf, int t) {
+        const long long k0 = (long long)t * 128;
+#pragma unroll
+        for (int p2 = 0; p2 < 4; ++p2) xf[buf][p2] = *reinterpret_cast<const bf16x8*>(xp + k0 + 32 * p2);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int p2 = 0; p2 < 4; ++p2) wf[buf][j][p2] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wp[j] + k0 + 32 * p2));
+    };
+    if (t0 < t1) load(0, t0);
+    for (int t = t0; t < t1; t += 2) {
+        if (t + 1 < t1) load(1, t + 1);
+#pragma unroll
+        for (int p2 = 0; p2 < 4; ++p2)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[0][j][p2], xf[0][p2], acc[j], 0, 0, 0);
+        if (t + 1 < t1) {
+            if (t + 2 < t1) load(0, t + 2);
+#pragma unroll
+            for (int p2 = 0; p2 < 4; ++p2)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[1][j][p2], xf[1][p2], acc[j], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[wave][16 * j + 4 * grp + r][nl] = acc[j][r];     // D: column m = lane & 15, row n = 4 (lane >> 4) + r
+    __syncthreads();
+    const int m = threadIdx.x >> 4, n4 = (threadIdx.x & 15) * 4;
+    if (m >= g.M) return;
+    float v[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = ((red[0][n4 + i][m] + red[1][n4 + i][m]) + red[2][n4 + i][m]) + red[3][n4 + i][m];
+    const int n = n0 + n4;
+    if (g.splitk > 1) {                                                  // this K slice's slab [M, N] fp32 (N % 4 == 0)
+        if (n < g.N) *reinterpret_cast<f32x4*>(g.ws + ((long long)blockIdx.y * g.M + m) * g.N + n) = (f32x4){v[0], v[1], v[2], v[3]};
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (n + i >= g.N) continue;
+        float xv = act_apply(v[i] * g.alpha + (g.bias ? bf2f(g.bias[n + i]) : 0.f), g.act);
+        TC* cp = reinterpret_cast<TC*>(g.C) + (long long)m * g.ldc + n + i;
+        if (g.residual) xv += Cvt<TC>::ld(reinterpret_cast<const TC*>(g.residual) + (long long)m * g.ldr + n + i);
+        if (g.accumulate) xv += Cvt<TC>::ld(cp);
+        Cvt<TC>::st(cp, xv);
+    }
+}
+
+// =================================================================================================
 // M <= 256 projections of the cached decode step (BASELINE.json configs[4], bs = 256: q|k|v, o_proj, gate|up, down_proj, lm_head against the
 // KV-cached token; HF LlamaAttention / LlamaMLP forward, modeling_llama.py:243-281,174-176).  One block owns ALL 256 rows x 128 columns, 8 waves
 // as 4 (M) x 2 (N) with the 64 x 64 accumulator layout of gemm_nt_bf16_kernel (same epilogue, same split-K slabs and consumers), and walks K in
@@ -1125,6 +1212,8 @@ extern "C" int egomi_gemm_kernel_id(const egomi_gemm_desc* d) {
 
 static bool slabs_form_ok(const egomi_gemm_desc* d);
 static int skinny_splitk(const egomi_gemm_desc* d, int nwg);
+static bool gemv_form(const egomi_gemm_desc* d);
+static int gemv_splitk(const egomi_gemm_desc* d);
 // 128 < M <= 256 with a long K and enough columns: the all-rows ring kernel (gemm_nt_bf16_m256_kernel).  EGOMI_GEMM_M256=0: the 128x128 kernel (A/B runs)
 static bool m256_form(const egomi_gemm_desc* d) {
     static int on = -1;
@@ -1146,7 +1235,7 @@ static int m256_splitk(const egomi_gemm_desc* d) {
 extern "C" int egomi_gemm_slab_count(const egomi_gemm_desc* d) {
     if (!d) return EGOMI_E_BADARG;
     if (d->force_generic || !fast_applicable(d) || !slabs_form_ok(d) || tile_choice(d) != 1) return 0;
-    const int sk = m256_form(d) ? m256_splitk(d) : skinny_splitk(d, ((d->M + 127) / 128) * ((d->N + 127) / 128));
+    const int sk = gemv_form(d) ? gemv_splitk(d) : (m256_form(d) ? m256_splitk(d) : skinny_splitk(d, ((d->M + 127) / 128) * ((d->N + 127) / 128)));
     return sk >= 2 ? sk : 0;
 }
 
@@ -1168,6 +1257,42 @@ static int skinny_splitk(const egomi_gemm_desc* d, int nwg) {
     return sk > 1 ? sk : 1;
 }
 
+// M <= 16 (gemv_m16_kernel).  EGOMI_GEMM_GEMV=0: the 128x128 kernel (A/B runs)
+static bool gemv_form(const egomi_gemm_desc* d) {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("EGOMI_GEMM_GEMV"); on = e ? atoi(e) : 1; }
+    return on && d->M <= 16 && d->K >= 1024 && d->K % 128 == 0 && d->N >= 64 && (d->epilogue == EGOMI_EPI_NONE || d->epilogue == EGOMI_EPI_SLABS);
+}
+static int gemv_splitk(const egomi_gemm_desc* d) {
+    const int nwg = (d->N + GV_BN - 1) / GV_BN, T = d->K / 128;
+    if (!d->workspace || (d->N & 3)) return 1;
+    // measured at M = 8 (tools/gemm_bench_decode.py 8, rotating weights): ~700 blocks of 4 waves (2.7 per CU) — q|k|v 4 slices 26.4 us (3 slices 29.8),
+    // o_proj 4 slices 14.0, gate|up 2 slices 40.9 (whole K 47.9, 3 slices 44.6), down_proj 4-8 slices 25.2-25.9, lm_head whole K 50.1 us = 5.3 TB/s
+    int sk = d->split_k > 0 ? d->split_k : (704 + nwg / 2) / nwg;
+    if (sk < 1) sk = 1;
+    if (sk > T / 8) sk = T / 8;
+    if (d->epilogue == EGOMI_EPI_SLABS && sk < 2 && T >= 16) sk = 2;
+    const long long per_slab = (long long)d->M * d->N * 4;
+    if ((long long)sk * per_slab > d->workspace_bytes) sk = (int)(d->workspace_bytes / per_slab);
+    return sk > 1 ? sk : 1;
+}
+static int launch_gemv(const egomi_gemm_desc* d, FastArgs& g, hipStream_t s) {
+    g.tiles_m = 1; g.tiles_n = (d->N + GV_BN - 1) / GV_BN;
+    g.ws = (float*)d->workspace;
+    g.splitk = gemv_splitk(d);
+    if (d->epilogue == EGOMI_EPI_SLABS && g.splitk < 2) return EGOMI_E_UNSUPPORTED;     // egomi_gemm_slab_count said so
+    if (d->c_dtype == EGOMI_BF16) EGOMI_LAUNCH(gemv_m16_kernel<bf16_t>, dim3(g.tiles_n, g.splitk), dim3(256), 0, s, g);
+    else if (d->c_dtype == EGOMI_F32) EGOMI_LAUNCH(gemv_m16_kernel<float>, dim3(g.tiles_n, g.splitk), dim3(256), 0, s, g);
+    else return EGOMI_E_UNSUPPORTED;
+    if (g.splitk > 1 && d->epilogue != EGOMI_EPI_SLABS) {
+        const long long total = (long long)d->M * ((d->N + 3) / 4);
+        const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+        if (d->c_dtype == EGOMI_BF16) EGOMI_LAUNCH(splitk_reduce_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, g);
+        else EGOMI_LAUNCH(splitk_reduce_kernel<float>, dim3(grid), dim3(256), 0, s, g);
+    }
+    return egomi_launch_status();
+}
+
 static int launch_m256(const egomi_gemm_desc* d, FastArgs& g, hipStream_t s) {
     g.tiles_m = 1; g.tiles_n = (d->N + 127) / 128;
     g.ws = (float*)d->workspace;
@@ -1187,6 +1312,7 @@ static int launch_m256(const egomi_gemm_desc* d, FastArgs& g, hipStream_t s) {
 
 template <int BM, int BN>
 static int launch_fast(const egomi_gemm_desc* d, FastArgs& g, hipStream_t s) {
+    if (BM == 128 && BN == 128 && gemv_form(d)) return launch_gemv(d, g, s);
     if (BM == 128 && BN == 128 && m256_form(d)) return launch_m256(d, g, s);
     g.tiles_m = (d->M + BM - 1) / BM; g.tiles_n = (d->N + BN - 1) / BN;
     const int nwg = g.tiles_m * g.tiles_n;

@@ -3,7 +3,7 @@ sizes (S % 32 == 0, M % 256 == 0, K % 64 == 0) as well as ragged ones (VERDICT r
 "every test size was ragged": a clamp that only a ragged last tile takes leaves the aligned fast path free to read past the last row.  A read
 past such an operand leaves its mapped segment (a fault), and results are compared bit for bit with the same call on ordinary allocations
 (a stray read that lands in mapped memory but feeds a result shows there).  Families: fused attention forward / backward (q|k|v, out, dout,
-dq|dk|dv, LSE, delta, key mask), the K-contiguous GEMMs (256x256 8-phase, 128x128, the M <= 256 ring kernel: A, B, C), the k-major 8-phase
+dq|dk|dv, LSE, delta, key mask), the K-contiguous GEMMs (256x256 8-phase, 128x128, the M <= 256 ring kernel, the M <= 16 weight-streaming kernel: A, B, C), the k-major 8-phase
 GEMM (weight- and data-gradient forms, a column-sliced operand whose width is not a multiple of 256: ADVICE r3), the decode attention's K/V
 cache.  One parametrised test per family; run once."""
 import math
@@ -75,7 +75,8 @@ def test_attention_operands_at_the_end_of_their_allocations(ops, S, causal):
 
 # (M, N, K): the 256x256 8-phase kernel (>= 128 tiles, K >= 2048) aligned and ragged; the 128x128 kernel; the M <= 256 ring kernel
 @pytest.mark.parametrize("M,N,K,kid", [(5632, 4096, 2048, 2), (5536, 4096, 2112, 2), (5632, 2048, 4096, 2), (1024, 1024, 512, 1), (1000, 1032, 576, 1),
-                                       (256, 4096, 4096, None), (256, 12288, 2048, None), (200, 8200, 2112, None)])
+                                       (256, 4096, 4096, None), (256, 12288, 2048, None), (200, 8200, 2112, None),
+                                       (8, 4096, 4096, None), (16, 12288, 2048, None), (5, 4100, 1152, None)])    # the last three: gemv_m16_kernel (M <= 16)
 def test_k_contiguous_gemm_operands_at_the_end_of_their_allocations(ops, M, N, K, kid):
     a0, w0 = rnd(M, K, seed=1).cuda(), rnd(N, K, seed=2, scale=0.05).cuda()
     ws = torch.zeros(64 << 20, dtype=torch.uint8, device="cuda")

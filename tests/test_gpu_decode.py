@@ -192,3 +192,37 @@ def test_generate_reuses_its_decoder_and_captured_loop_across_calls():
     s2 = m.generate(input_ids=toks[:2, :Lp].cuda(), attention_mask=masks[:2, :Lp].cuda(), point_clouds=pts[:2], max_length=5, do_sample=True, fps_start=[0, 17], seed=3)
     assert torch.equal(s1.sequences, s2.sequences)                         # the replayed sampling loop reads the seed from device memory
     assert len(dec._graphs) >= 2                                           # greedy and sampled loops are different captures of the same decoder
+
+
+@pytest.mark.parametrize("M,N,K", [(8, 12288, 4096), (8, 4096, 4096), (16, 22016, 4096), (8, 4096, 11008), (1, 32262, 4096), (5, 200, 1024), (16, 4100, 1152)])
+def test_gemv_m16_kernel_matches_reference(M, N, K):
+    """gemv_m16_kernel (round 4: M <= 16, the decode projections at the reference's evaluation batch size — weight rows streamed from HBM to
+    registers, x as the other MFMA operand, K cut over slices x 4 waves) against the fp32 product of the same bf16 operands: unsplit, the
+    library's split plan + combine pass, an explicit split with fp32 output, the full epilogue, unsummed slabs (EGOMI_EPI_SLABS), ragged N,
+    one row; EGOMI_GEMM_GEMV=0 is read once per process, so the A/B against the 128x128 kernel lives in tools/debug/validation_throughput.py."""
+    from egoscaler_amd import ops
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.randn(M, K, generator=g).bfloat16()
+    w = (torch.randn(N, K, generator=g) * 0.05).bfloat16()
+    A, W = a.cuda(), w.cuda()
+    ref = a.float() @ w.float().t()
+    tol = 2e-2
+    ws = torch.zeros(64 << 20, dtype=torch.uint8, device="cuda")
+    out = ops.mm(A, W)                                                        # no workspace: every K slice in one block
+    assert float((out.float().cpu() - ref).abs().max()) <= tol * float(ref.abs().max())
+    out_ws = ops.mm(A, W, workspace=ws)                                       # the library's plan (split + combine where N is small)
+    assert float((out_ws.float().cpu() - ref).abs().max()) <= tol * float(ref.abs().max())
+    if N % 4 == 0:
+        out32 = ops.mm(A, W, out_dtype=torch.float32, workspace=ws, split_k=3)
+        assert float((out32.cpu() - ref).abs().max()) <= 2e-3 * float(ref.abs().max())
+    bias = torch.randn(N, generator=g).bfloat16().cuda()
+    res = torch.randn(M, N, generator=g).bfloat16().cuda()
+    full = ops.mm(A, W, bias=bias, residual=res, act=ops.ACT_GELU, alpha=0.5, workspace=ws)
+    want = torch.nn.functional.gelu(0.5 * ref + bias.float().cpu()) + res.float().cpu()
+    assert float((full.float().cpu() - want).abs().max()) <= tol * float(want.abs().max())
+    if N % 4 == 0:
+        n = ops.mm_slabs(A, W, out, ws, count_only=True)
+        if n >= 2:
+            assert ops.mm_slabs(A, W, out, ws) == n
+            slabs = torch.frombuffer(ws.cpu().numpy().tobytes(), dtype=torch.float32)[:n * M * N].view(n, M, N)
+            assert float((slabs.sum(0) - ref).abs().max()) <= 2e-3 * float(ref.abs().max())
