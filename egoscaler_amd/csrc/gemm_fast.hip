@@ -815,6 +815,240 @@ void gemm_nt_bf16_8phase_kernel(FastArgs g) {
 
 
 // =================================================================================================
+// 352x256 tile: the 8-phase schedule with 11 instead of 8 row blocks per wave (2 M x 4 N waves, 176x64 each) — the form for
+// products whose 256x256 tiles leave a ragged last round.  At M = 5536, N = 4096 (o_proj, down_proj and three of the four
+// data gradients of a LLaMA layer: 54 % of the step's GEMM flops) 22 x 16 = 352 tiles of 256x256 are 1.375 rounds on 256 CUs,
+// which the K-sliced tail runs in 1.56-1.64 tile-times; 16 x 16 = 256 tiles of 352x256 are exactly ONE round of 1.375
+// tile-times: no slabs, no combine pass, one prologue / epilogue per CU.  (tall_form() below picks per shape.)
+//   LDS  : 2 buffers x (A [352 rows][64 k] + B [256 rows][64 k]) bf16 = 152 KB, rows in tile order, same XOR swizzle.
+//          Sub-tiles by CONSUMPTION order: A-c0 / c1 / c2 = row blocks 0-3 / 4-7 / 8-10 of both wave rows, B-h0 / h1 =
+//          columns 0-31 / 32-63 of all four wave columns.
+//   tile t (buffer b), six phases of [ds_read + DMA issue | barrier | MFMA cluster | barrier], wave groups one barrier apart:
+//          ph1 reads B-h0, A-c0   MFMA (c0,h0) 16   DMA A-c2(t+1) -> b^1
+//          ph2 reads B-h1         MFMA (c0,h1) 16   DMA B-h0(t+2) -> b   (B-h0 reads retired by lgkmcnt(8) in ph1)
+//          ph3 reads A-c1         MFMA (c1,h1) 16   DMA A-c0(t+2) -> b
+//          ph4 (h0 kept in regs)  MFMA (c1,h0) 16   DMA B-h1(t+2) -> b
+//          ph5 reads A-c2         MFMA (c2,h0) 12   DMA A-c1(t+2) -> b
+//          ph6 (h1 kept in regs)  MFMA (c2,h1) 12   vmcnt(8): tile t+1 has landed
+//          A sub-tile is refilled no earlier than two phases after its last read (or one, with the reads retired before the
+//          barrier), because the other wave group runs one barrier behind.
+//   DMA  : inline asm, scalar base + one 32-bit per-lane offset per operand: every 8-row group a wave fetches has the wave's
+//          own parity, so the swizzled source offset inside a group is the same VGPR for all of them; the group's row offset
+//          is scalar.  Needs M % 8 == 0 and N % 8 == 0 (a ragged tile clamps whole 8-row groups), M, N >= 8.
+//   88 MFMAs per K-tile and wave on 30 ds_read_b128 (0.34 per MFMA; the 256x256 form: 0.375), 10 (9) DMA instructions.
+// =================================================================================================
+#define TL_NB 11
+#define TL_BM (32 * TL_NB)
+#define TL_AB (TL_BM * 128)                       // bytes of the A image of one buffer
+#define TL_BUFB (TL_AB + 256 * 128)               // bytes per buffer
+__device__ __forceinline__ void tl_dma(const char* gbase, uint32_t voff, uint32_t lds_base) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voff), "s"(gbase), "s"(lds_base) : "memory");
+}
+template <typename TC>
+__global__ __launch_bounds__(512, 2)
+void gemm_nt_bf16_tall_kernel(FastArgs g) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * TL_BUFB];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+
+    int tm, tn;
+    {                                                                 // XCD-aware strips, 8 tile rows deep (as the 256x256 kernel)
+        const int nwg = gridDim.x;
+        int bid = blockIdx.x;
+        const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+        const int per_group = 8 * g.tiles_n;
+        const int grp = bid / per_group, first_tm = grp * 8;
+        const int gsz = (g.tiles_m - first_tm) < 8 ? (g.tiles_m - first_tm) : 8;
+        const int in_g = bid - grp * per_group;
+        tm = first_tm + in_g % gsz; tn = in_g / gsz;
+    }
+    const int m0 = tm * TL_BM, n0 = tn * 256;
+
+    // ---- the 8-row groups this wave fetches (index = tile row / 8): A-c0 {w, 22+w}, A-c1 {8+w, 30+w}, A-c2 {16..21, 38, 39 by wave} + {40+w, waves 0-3},
+    //      B-h {(w>>2)*8 + 4h + (w&3), +16}: all of parity w & 1
+    const int ga2 = wave < 6 ? 16 + wave : 32 + wave;
+    const int gA[3][2] = {{wave, 22 + wave}, {8 + wave, 30 + wave}, {ga2, 40 + (wave & 3)}};
+    const int gb = (wave >> 2) * 8 + (wave & 3);
+    uint32_t sA[3][2], sB[2][2], lA[3][2], lB[2][2];
+    const uint32_t lds0 = (uint32_t)(uintptr_t)((lds_void*)smem);
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            int r = m0 + gA[c][i] * 8; r = r < g.M - 8 ? r : g.M - 8;
+            sA[c][i] = __builtin_amdgcn_readfirstlane((uint32_t)(r * (int)g.lda) * 2u);
+            lA[c][i] = __builtin_amdgcn_readfirstlane(lds0 + gA[c][i] * 1024);
+        }
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int gi = gb + 4 * h + 16 * i;
+            int r = n0 + gi * 8; r = r < g.N - 8 ? r : g.N - 8;
+            sB[h][i] = __builtin_amdgcn_readfirstlane((uint32_t)(r * (int)g.ldb) * 2u);
+            lB[h][i] = __builtin_amdgcn_readfirstlane(lds0 + TL_AB + gi * 1024);
+        }
+    const uint32_t dchunk = (lane & 7) ^ ((((wave & 1) << 2) + (lane >> 4)) & 7);
+    const uint32_t vA = (uint32_t)((lane >> 3) * (int)g.lda + (int)dchunk * 8) * 2u;
+    const uint32_t vB = (uint32_t)((lane >> 3) * (int)g.ldb + (int)dchunk * 8) * 2u;
+
+    f32x4 acc[4][TL_NB];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < TL_NB; ++i) acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // fragment read offsets (bytes) inside a buffer
+    const int sw = ((lane & 15) >> 1) & 7, c0 = lane >> 4;
+    int aRd[2], bRd[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        aRd[ks] = (wr * (16 * TL_NB) + (lane & 15)) * 128 + (((c0 + 4 * ks) ^ sw) << 4);
+        bRd[ks] = TL_AB + (wc * 64 + (lane & 15)) * 128 + (((c0 + 4 * ks) ^ sw) << 4);
+    }
+    const int nt = g.K / FT_BK, t_last = nt - 1;
+    const char* Ab = reinterpret_cast<const char*>(g.A);
+    const char* Bb = reinterpret_cast<const char*>(g.B);
+
+    bf16x8 fa[2][4], fb0[2][2], fb1[2][2];
+    // (bo = byte offset of the tile's buffer, bn = of the other one: scalars; the per-lane read offsets aRd / bRd are advanced from buffer to buffer,
+    //  because buffer 1's fragments lie beyond the 64-KB reach of a ds_read immediate and a second set of base registers does not fit 256 VGPRs)
+#define TL_RD(off) (*reinterpret_cast<const bf16x8*>(smem + (off)))
+#define TL_LDA(c, n) _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int ii = 0; ii < (n); ++ii) \
+        fa[ks][ii] = TL_RD(aRd[ks] + ((c) * 64 + ii * 16) * 128);
+#define TL_LDB(dst, X) _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int jj = 0; jj < 2; ++jj) \
+        dst[ks][jj] = TL_RD(bRd[ks] + ((X) * 32 + jj * 16) * 128);
+#define TL_PFA(bo_, c, base) { tl_dma((base) + sA[c][0], vA, lA[c][0] + (bo_)); \
+        if ((c) < 2 || wave < 4) tl_dma((base) + sA[c][1], vA, lA[c][1] + (bo_)); }
+#define TL_PFB(bo_, h, base) { tl_dma((base) + sB[h][0], vB, lB[h][0] + (bo_)); tl_dma((base) + sB[h][1], vB, lB[h][1] + (bo_)); }
+#define TL_MMA(c, n, fbv, X) __builtin_amdgcn_s_setprio(1); \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int jj = 0; jj < 2; ++jj) _Pragma("unroll") for (int ii = 0; ii < (n); ++ii) \
+            acc[(X) * 2 + jj][(c) * 4 + ii] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fbv[ks][jj], fa[ks][ii], acc[(X) * 2 + jj][(c) * 4 + ii], 0, 0, 0); \
+        __builtin_amdgcn_s_setprio(0);
+#define TL_BAR __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0);
+
+    // ---- prologue: tile 0 complete, all but A-c2 of tile 1 in flight
+    {
+        const int t1 = 1 < t_last ? 1 : t_last;
+        const char* pA1 = Ab + (long long)t1 * 128;
+        const char* pB1 = Bb + (long long)t1 * 128;
+        TL_PFB(0, 0, Bb) TL_PFA(0, 0, Ab) TL_PFB(0, 1, Bb) TL_PFA(0, 1, Ab) TL_PFA(0, 2, Ab)
+        TL_PFB(TL_BUFB, 0, pB1) TL_PFA(TL_BUFB, 0, pA1) TL_PFB(TL_BUFB, 1, pB1) TL_PFA(TL_BUFB, 1, pA1)
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        TL_BAR
+    }
+    if (wr == 1) { TL_BAR }                                       // second wave group runs one barrier behind
+#pragma unroll 1
+    for (int t = 0; t < nt; ++t) {
+        const uint32_t bo = (t & 1) ? TL_BUFB : 0, bn = TL_BUFB - bo;
+        const int t1 = t + 1 < t_last ? t + 1 : t_last, t2 = t + 2 < t_last ? t + 2 : t_last;
+        const char* pA1 = Ab + (long long)t1 * 128;
+        const char* pA2 = Ab + (long long)t2 * 128;
+        const char* pB2 = Bb + (long long)t2 * 128;
+        /* ph1 */ TL_LDB(fb0, 0) __builtin_amdgcn_sched_barrier(0); TL_LDA(0, 4) TL_PFA(bn, 2, pA1)
+        asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory"); TL_BAR TL_MMA(0, 4, fb0, 0) TL_BAR
+        /* ph2 */ TL_LDB(fb1, 1) TL_PFB(bo, 0, pB2) TL_BAR TL_MMA(0, 4, fb1, 1) TL_BAR
+        /* ph3 */ TL_LDA(1, 4) TL_PFA(bo, 0, pA2) TL_BAR TL_MMA(1, 4, fb1, 1) TL_BAR
+        /* ph4 */ TL_PFB(bo, 1, pB2) TL_BAR TL_MMA(1, 4, fb0, 0) TL_BAR
+        /* ph5 */ TL_LDA(2, 3) TL_PFA(bo, 1, pA2) TL_BAR TL_MMA(2, 3, fb0, 0) TL_BAR
+        /* ph6 */ asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        {
+            const int dl = (t & 1) ? -TL_BUFB : TL_BUFB;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) { aRd[ks] += dl; bRd[ks] += dl; }
+        }
+        TL_BAR TL_MMA(2, 3, fb1, 1) TL_BAR
+    }
+    if (wr == 0) { TL_BAR }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // the tail's redundant DMAs drain before the stages are re-used below
+    __builtin_amdgcn_s_barrier();
+#undef TL_BAR
+#undef TL_MMA
+#undef TL_PFB
+#undef TL_PFA
+#undef TL_LDB
+#undef TL_LDA
+#undef TL_RD
+    const int mb = m0 + wr * (16 * TL_NB), nb = n0 + wc * 64;
+    if (sizeof(TC) == 2 && !g.bias && !g.accumulate && g.act == 0 && g.alpha == 1.0f && nb + 64 <= g.N && (g.ldc & 7) == 0 && ((uintptr_t)g.C & 15) == 0 &&
+        (!g.residual || ((g.ldr & 7) == 0 && ((uintptr_t)g.residual & 15) == 0))) {      // wave-uniform
+        bf16_t* C = reinterpret_cast<bf16_t*>(g.C);
+        if (g.residual) {
+            // bf16 tile + residual (o_proj, down_proj): the direct form stores 8-B pieces of 16 rows per instruction; here 64 rows x 64 columns of fp32
+            // go through a wave-private strip (272-B pitch) and leave as 128-B row segments, the residual rows arriving the same way.
+            // Same arithmetic as gemm_epilogue: fp32 sum, one rounding.
+            char* wb = smem + wave * (64 * 272);
+            const bf16_t* R = reinterpret_cast<const bf16_t*>(g.residual);
+            const int lr = lane >> 3, ch = lane & 7;
+#pragma unroll
+            for (int pass = 0; pass < 3; ++pass) {
+                const int nblk = (TL_NB - 4 * pass) < 4 ? (TL_NB - 4 * pass) : 4;
+                u32x4 rr[8];
+#pragma unroll
+                for (int it = 0; it < 8; ++it) {
+                    if (it * 8 >= nblk * 16) continue;
+                    int m = mb + pass * 64 + it * 8 + lr; m = m < g.M ? m : g.M - 1;
+                    rr[it] = *reinterpret_cast<const u32x4*>(R + (long long)m * g.ldr + nb + ch * 8);
+                }
+#pragma unroll
+                for (int ii = 0; ii < 4; ++ii) {
+                    if (ii >= nblk) continue;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        *reinterpret_cast<f32x4*>(wb + (ii * 16 + (lane & 15)) * 272 + (j * 16 + (lane >> 4) * 4) * 4) = acc[j][4 * pass + ii];
+                }
+#pragma unroll
+                for (int it = 0; it < 8; ++it) {
+                    if (it * 8 >= nblk * 16) continue;
+                    const f32x4 x0 = *reinterpret_cast<const f32x4*>(wb + (it * 8 + lr) * 272 + ch * 32);
+                    const f32x4 x1 = *reinterpret_cast<const f32x4*>(wb + (it * 8 + lr) * 272 + ch * 32 + 16);
+                    u32x4 o;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float lo = (q < 2 ? x0[2 * q] : x1[2 * q - 4]) + __uint_as_float(rr[it][q] << 16);
+                        const float hi = (q < 2 ? x0[2 * q + 1] : x1[2 * q - 3]) + __uint_as_float(rr[it][q] & 0xFFFF0000u);
+                        o[q] = (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+                    }
+                    const int m = mb + pass * 64 + it * 8 + lr;
+                    if (m < g.M) *reinterpret_cast<u32x4*>(C + (long long)m * g.ldc + nb + ch * 8) = o;
+                }
+            }
+            return;
+        }
+        // plain bf16 store through a wave-private LDS strip (64 rows x 144-B pitch) as 128-B row segments, as the 256x256 kernel
+        char* wb = smem + wave * (64 * 144);
+#pragma unroll
+        for (int pass = 0; pass < 3; ++pass) {
+#pragma unroll
+            for (int ii = 0; ii < 4; ++ii) {
+                if (4 * pass + ii >= TL_NB) continue;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const f32x4 v = acc[j][4 * pass + ii];
+                    u32x2 o;
+                    o[0] = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+                    o[1] = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+                    *reinterpret_cast<u32x2*>(wb + (ii * 16 + (lane & 15)) * 144 + (j * 16 + (lane >> 4) * 4) * 2) = o;
+                }
+            }
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int r = it * 8 + (lane >> 3), ch = lane & 7;
+                if (4 * pass * 16 + it * 8 >= 16 * TL_NB) continue;
+                const u32x4 v = *reinterpret_cast<const u32x4*>(wb + r * 144 + ch * 16);
+                const int m = mb + pass * 64 + r;
+                if (m < g.M) *reinterpret_cast<u32x4*>(C + (long long)m * g.ldc + nb + ch * 8) = v;
+            }
+        }
+        return;
+    }
+    gemm_epilogue<TC, TL_NB>(g, acc, mb, nb, lane);
+}
+
+
+// =================================================================================================
 // Persistent form of the 8-phase kernel: ONE 512-thread block per CU walks a static list of work items, and the LDS-DMA
 // pipeline never drains between them (the two K-tiles the schedule keeps in flight are simply the next item's first two).
 //   items of block b (G = grid = number of CUs, T = tiles, nt = K-tiles per tile, even):
@@ -1453,6 +1687,42 @@ static int launch_p8(const egomi_gemm_desc* d, FastArgs& g, const P8Sched& sc, h
     return egomi_launch_status();
 }
 
+// ---- 352x256 form (gemm_nt_bf16_tall_kernel).  EGOMI_GEMM_TALL / egomi_gemm_set_tall: 0 never, 2 wherever it applies (A/B runs, tests), 1 (default) by the
+// round model below, in 256x256 tile-times, fitted to tools/debug/tall_probe.py at M = 5536 (cold weights, one box):
+//   256x256 plan: whole rounds + (0.28 + 0.85 x fill) for a ragged last round whose rows are K-sliced (1.6 for 1.375 rounds at N = 4096, 4.39 for 4.125 at N = 12288)
+//   352x256 plan: 1.31 per round of its own tiles (1.375 x the flops; 0.34 instead of 0.375 ds_read per MFMA and 12 instead of 16 barriers per 128 MFMAs)
+//   N = 4096: K = 4096 183.5 -> 158.8 us, K = 11008 404.9 -> 355.9, K = 12288 452.7 -> 382.1, K = 22016 758.0 -> 712.7; N = 12288 425.9 -> 399.9;
+//   N = 11008 / 22016 (0.70 / 0.39 of a round left over, 688 / 1376 tall tiles = 2.69 / 5.375 rounds): 373.8 vs 376.2, 746.9 vs 753.1 — stay on the 256x256 form
+static int g_tall_mode = -1;
+extern "C" int egomi_gemm_set_tall(int mode) { g_tall_mode = mode < 0 ? -1 : (mode > 2 ? 2 : mode); return EGOMI_OK; }
+static bool tall_form(const egomi_gemm_desc* d) {
+    if (g_tall_mode < 0) { const char* e = getenv("EGOMI_GEMM_TALL"); g_tall_mode = e ? atoi(e) : 1; if (g_tall_mode < 0 || g_tall_mode > 2) g_tall_mode = 1; }
+    const int mode = g_tall_mode;
+    if (!mode) return false;
+    if (d->epilogue != EGOMI_EPI_NONE && d->epilogue != EGOMI_EPI_SLABS) return false;
+    if ((d->M & 7) || (d->N & 7) || d->M < TL_BM || d->N < 256 || d->K < 2048 || d->split_k > 1) return false;      // (split_k = 1: "no K-sliced rows", the tests' way to compare whole tiles of both forms)
+    if ((long long)d->M * d->lda >= (1ll << 31) || (long long)d->N * d->ldb >= (1ll << 31)) return false;
+    if (d->c_dtype != EGOMI_BF16 && d->c_dtype != EGOMI_F32) return false;
+    if (mode == 2) return true;
+    const int ncu = 256;
+    const long long tn = (d->N + 255) / 256;
+    const long long t256 = (long long)((d->M + 255) / 256) * tn, t352 = (long long)((d->M + TL_BM - 1) / TL_BM) * tn;
+    const int rem = (int)(t256 % ncu);
+    const double c256 = (double)(t256 / ncu) + (rem ? (rem * 2 <= ncu && d->workspace ? 0.28 + 0.85 * rem / ncu : 1.0) : 0.0);
+    const double c352 = 1.31 * (double)((t352 + ncu - 1) / ncu);
+    return c352 < 0.98 * c256;
+}
+static int launch_tall(const egomi_gemm_desc* d, FastArgs& g, hipStream_t s, hipEvent_t t0, hipEvent_t t1) {
+    g.tiles_m = (d->M + TL_BM - 1) / TL_BM; g.tiles_n = (d->N + 255) / 256;
+    g.splitk = 1; g.ws = nullptr; g.tickets = nullptr; g.epi = 0;
+    const int nwg = g.tiles_m * g.tiles_n;
+    if (t0) (void)hipEventRecord(t0, s);
+    if (d->c_dtype == EGOMI_BF16) EGOMI_LAUNCH(gemm_nt_bf16_tall_kernel<bf16_t>, dim3(nwg), dim3(512), 0, s, g);
+    else EGOMI_LAUNCH(gemm_nt_bf16_tall_kernel<float>, dim3(nwg), dim3(512), 0, s, g);
+    if (t1) (void)hipEventRecord(t1, s);
+    return egomi_launch_status();
+}
+
 // the tail plan launch_8phase will run for this descriptor (d->workspace already points at the slab area)
 static TailPlan tail_plan_for(const egomi_gemm_desc* d) {
     const int tiles_m = (d->M + 255) / 256;
@@ -1491,6 +1761,7 @@ extern "C" int egomi_gemm_tail_plan(const egomi_gemm_desc* d0, int* row0, int* s
         if (dl.workspace_bytes > 4096) { dl.workspace = (char*)dl.workspace + 4096; dl.workspace_bytes -= 4096; }
         else { dl.workspace = nullptr; dl.workspace_bytes = 0; }
     }
+    if (tall_form(&dl)) return EGOMI_OK;                               // one round of 352x256 tiles: no K-sliced rows
     const TailPlan tp = tail_plan_for(&dl);
     if (tp.rows) { *row0 = ((dl.M + 255) / 256 - tp.rows) * 256; *slices = tp.s; }
     return EGOMI_OK;
@@ -1564,6 +1835,10 @@ int egomi_gemm_fast_try(const egomi_gemm_desc* d0, hipStream_t s) {
     g.alpha = d->alpha; g.accumulate = d->accumulate; g.act = d->act; g.tickets = nullptr;
     g.epi = d->epilogue; g.C2 = d->C2; g.ldc2 = d->ldc2;
     const int tc = tile_choice(d);
+    if (tc == 8 && tall_form(d)) {
+        if (d->epilogue == EGOMI_EPI_SLABS && (d->bias || d->accumulate || d->act != 0 || d->alpha != 1.0f || d->c_dtype != EGOMI_BF16)) return EGOMI_E_UNSUPPORTED;
+        return launch_tall(d, g, s, t0, t1);
+    }
     if (d->epilogue == EGOMI_EPI_SLABS && tc == 8) {
         // large products: only the K-sliced TAIL rows are left as slabs (egomi_gemm_tail_plan tells which); whole tiles get the
         // normal epilogue, residual included

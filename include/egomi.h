@@ -161,9 +161,15 @@ typedef struct egomi_gemm_desc {
 #define EGOMI_EPI_SLABS 2
 #define EGOMI_EPI_SWIGLU_BWD 3
 int egomi_gemm(const egomi_gemm_desc* desc, egomi_stream_t stream);
-/* which kernel egomi_gemm would run for this descriptor: 2 = 256x256 8-phase bf16 NT kernel (either form), 1 = 128x128 / 256x128 bf16
- * NT kernel, 0 = generic */
+/* which kernel egomi_gemm would run for this descriptor: 2 = the 8-phase bf16 NT kernel (256x256 tiles, per-tile or persistent, or the
+ * 352x256 form below), 1 = 128x128 / 256x128 bf16 NT kernel, 0 = generic */
 int egomi_gemm_kernel_id(const egomi_gemm_desc* desc);
+/* 352x256 form of the 8-phase kernel (gemm_nt_bf16_tall_kernel): one whole round where 256x256 tiles leave a ragged last one (M = 5536, N = 4096:
+ * 256 tiles instead of 352).  mode 0 = never, 1 = by the library's round model (default), 2 = wherever it applies (M % 8 == 0, N % 8 == 0,
+ * M >= 352, K >= 2048, plain or EGOMI_EPI_SLABS epilogue), -1 = back to EGOMI_GEMM_TALL / the default.  A product that takes this form has no
+ * K-sliced tail rows (egomi_gemm_tail_plan: slices = 0).  Full tiles are bit-identical to the 256x256 form's (same K order per element).
+ * Process-wide, not thread-safe: measurement and tests only.  No reference counterpart (torch.nn.Linear's GEMM is the vendor library's). */
+int egomi_gemm_set_tall(int mode);
 int egomi_gemm_slab_count(const egomi_gemm_desc* desc);   /* EGOMI_EPI_SLABS: slices egomi_gemm will leave for this descriptor, 0 = none */
 /* EGOMI_EPI_SLABS on a LARGE product (egomi_gemm_kernel_id == 2): whole 256-row tiles get the normal epilogue (residual
  * included); the K-sliced tail rows [row0, M) are left as `slices` fp32 slabs [slices][M - row0][N] at the start of the slab

@@ -496,11 +496,18 @@ def test_gemm_swiglu_epilogue(ops, M, Fd, K):
     the plain product and C2 equals egomi_swiglu_il_fwd(C) bit for bit, on whole tiles, ragged M and K-sliced tail rows; shapes
     the fused path cannot serve are refused, never silently computed without C2."""
     from egoscaler_amd import _lib
+    import ctypes
     x = rnd(M, K, dtype=torch.bfloat16, seed=51).cuda()
     wg, wu = rnd(Fd, K, dtype=torch.bfloat16, seed=52, scale=0.05).cuda(), rnd(Fd, K, dtype=torch.bfloat16, seed=53, scale=0.05).cuda()
     w = torch.stack([wg.view(Fd // 32, 32, K), wu.view(Fd // 32, 32, K)], 1).reshape(2 * Fd, K).contiguous()
     assert ops.gemm_kernel_id(M, 2 * Fd, K) == 2
-    gu_ref = ops.mm(x, w)
+    # the fused epilogue lives in the 256x256 form: the plain reference product takes that form too (same K-sliced tail rows, same bits);
+    # the 352x256 form would sum those rows' K-tiles in one run
+    _lib.lib().egomi_gemm_set_tall(ctypes.c_int(0))
+    try:
+        gu_ref = ops.mm(x, w)
+    finally:
+        _lib.lib().egomi_gemm_set_tall(ctypes.c_int(-1))
     act_ref = ops.swiglu_il(gu_ref, torch.empty(M, Fd, dtype=torch.bfloat16, device="cuda"))
     gu = torch.empty_like(gu_ref)
     act = torch.full((M, Fd), 7.0, dtype=torch.bfloat16, device="cuda")

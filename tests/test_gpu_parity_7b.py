@@ -196,12 +196,17 @@ def test_bf16_7b_width_frozen_equals_unfrozen_on_shared_gradients(wide):
         assert fro < 1.5e-2, (n, fro, mx)
 
 
-def test_bf16_7b_width_tail_rows_summed_by_the_norms_change_nothing(wide):
+def test_bf16_7b_width_tail_rows_summed_by_the_norms_change_nothing(wide, request):
     """K-sliced tail rows of o_proj / down_proj (forward) and of the qkv / gate|up dgrads (backward, frozen layers) left as fp32
     slabs and summed by the RMSNorm kernel that reads them (EGOMI_EPI_SLABS, egomi_rmsnorm_fwd_tail / _bwd_tail) vs the separate
     combine pass: the same bits reach the loss, the hidden state and the gradients."""
     dims, toks, masks, Lp, pts, start, sd, ref = wide
     res = {}
+    import ctypes
+    from egoscaler_amd import _lib
+    # the 256x256 form with its K-sliced tail rows (at this size the library would otherwise take the 352x256 form for these products, which has none)
+    _lib.lib().egomi_gemm_set_tall(ctypes.c_int(0))
+    request.addfinalizer(lambda: _lib.lib().egomi_gemm_set_tall(ctypes.c_int(-1)))
     for fuse in (True, False):
         m = _model(dims, sd, False)
         m.engine.use_tail_fuse = fuse
