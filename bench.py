@@ -354,7 +354,7 @@ def main():
             sync._exposed.clear()
         prof = None
         if gemm_event_steps is not None:
-            prof = ops.GemmProfiler(min_flops=0, kernel_ids=(2,))          # the dominant kernel only: gemm_nt_bf16_8phase_kernel
+            prof = ops.GemmProfiler(min_flops=0, kernel_ids=(2,))          # the dominant kernel only: the 8-phase GEMM, both tile forms
             ops.PROFILER = prof
         marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
         barrier()
@@ -407,7 +407,8 @@ def main():
                                "passes over `bench.py --steps 1 --warmup 1` (%s)" % (os.path.basename(pj), rec.get("recorded", "round and commit in profiles/README.md")))
             except Exception:
                 traffic = None
-        roof = {"bound": "mfma", "kernel": "gemm_nt_bf16_8phase_kernel (every launch of %d of the %d timed steps; HIP events recorded by the library on the launch "
+        roof = {"bound": "mfma", "kernel": "the 8-phase bf16 GEMM = gemm_nt_bf16_8phase_kernel (256x256 tiles) + gemm_nt_bf16_tall_kernel (its 352x256 form; egomi_gemm_kernel_id 2: "
+                                           "in rocprofv3's kernel stats the two rows together, weighted by their calls) (every launch of %d of the %d timed steps; HIP events recorded by the library on the launch "
                                            "stream directly around the kernel, inside the timed region: egomi_gemm_time_next.  avg_call_ms is the whole egomi_gemm call, "
                                            "i.e. plus splitk_reduce_kernel where the tail rows are K-sliced)" % (len(ev_steps), a.steps),
                 "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS,

@@ -824,14 +824,16 @@ void gemm_nt_bf16_8phase_kernel(FastArgs g) {
 //          Sub-tiles by CONSUMPTION order: A-c0 / c1 / c2 = row blocks 0-3 / 4-7 / 8-10 of both wave rows, B-h0 / h1 =
 //          columns 0-31 / 32-63 of all four wave columns.
 //   tile t (buffer b), six phases of [ds_read + DMA issue | barrier | MFMA cluster | barrier], wave groups one barrier apart:
-//          ph1 reads B-h0, A-c0   MFMA (c0,h0) 16   DMA A-c2(t+1) -> b^1
-//          ph2 reads B-h1         MFMA (c0,h1) 16   DMA B-h0(t+2) -> b   (B-h0 reads retired by lgkmcnt(8) in ph1)
-//          ph3 reads A-c1         MFMA (c1,h1) 16   DMA A-c0(t+2) -> b
-//          ph4 (h0 kept in regs)  MFMA (c1,h0) 16   DMA B-h1(t+2) -> b
-//          ph5 reads A-c2         MFMA (c2,h0) 12   DMA A-c1(t+2) -> b
-//          ph6 (h1 kept in regs)  MFMA (c2,h1) 12   vmcnt(8): tile t+1 has landed
-//          A sub-tile is refilled no earlier than two phases after its last read (or one, with the reads retired before the
-//          barrier), because the other wave group runs one barrier behind.
+//          ph1 reads A-c0                 MFMA (c0,h0) 16
+//          ph2 reads B-h1                 MFMA (c0,h1) 16   DMA B-h0(t+2) -> b
+//          ph3 reads A-c1                 MFMA (c1,h1) 16   DMA A-c0(t+2) -> b
+//          ph4 (h0 kept in regs)          MFMA (c1,h0) 16   DMA B-h1(t+2) -> b ; vmcnt(6): A-c2(t+1) and everything before it has landed
+//          ph5 reads A-c2                 MFMA (c2,h0) 12   DMA A-c1(t+2) -> b
+//          ph6 reads B-h0 of tile t+1     MFMA (c2,h1) 12   DMA A-c2(t+1) -> b^1 (h1 kept in regs; h0's registers are free after ph5)
+//          A sub-tile is refilled no earlier than two phases after its last read, because the other wave group runs one barrier
+//          behind.  No read stage carries more than 8 ds_read_b128 + 2 DMA pieces per wave: a group's read stage runs under the other
+//          group's MFMA cluster, and 4 waves x (12 reads + 2 pieces) did not fit under 16 MFMAs (first version: ph1 read B-h0 AND
+//          A-c0; tools/debug/tall_ablate.py).
 //   DMA  : inline asm, scalar base + one 32-bit per-lane offset per operand: every 8-row group a wave fetches has the wave's
 //          own parity, so the swizzled source offset inside a group is the same VGPR for all of them; the group's row offset
 //          is scalar.  Needs M % 8 == 0 and N % 8 == 0 (a ragged tile clamps whole 8-row groups), M, N >= 8.
@@ -929,7 +931,18 @@ void gemm_nt_bf16_tall_kernel(FastArgs g) {
         __builtin_amdgcn_s_setprio(0);
 #define TL_BAR __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0);
 
-    // ---- prologue: tile 0 complete, all but A-c2 of tile 1 in flight
+    // (TL_ABL: timing-only ablation builds of tools/debug/tall_ablate.py — 1 no fragment reads, 2 no DMA, 4 one barrier per phase, 8 no MFMA, 16 every DMA reads K-tile 0; results are garbage)
+#ifndef TL_ABL
+#define TL_ABL 0
+#endif
+#define TL_LDA_(c, n) if (!(TL_ABL & 1)) { TL_LDA(c, n) }
+#define TL_LDB_(dst, X) if (!(TL_ABL & 1)) { TL_LDB(dst, X) }
+#define TL_PFA_(bo_, c, base) if (!(TL_ABL & 2)) { TL_PFA(bo_, c, base) }
+#define TL_PFB_(bo_, h, base) if (!(TL_ABL & 2)) { TL_PFB(bo_, h, base) }
+#define TL_MMA_(c, n, fbv, X) if (!(TL_ABL & 8)) { TL_MMA(c, n, fbv, X) }
+#define TL_BAR2 if (!(TL_ABL & 4)) { TL_BAR }
+
+    // ---- prologue: tile 0 complete, all but A-c2 of tile 1 in flight; B-h0 of tile 0 in registers
     {
         const int t1 = 1 < t_last ? 1 : t_last;
         const char* pA1 = Ab + (long long)t1 * 128;
@@ -938,28 +951,31 @@ void gemm_nt_bf16_tall_kernel(FastArgs g) {
         TL_PFB(TL_BUFB, 0, pB1) TL_PFA(TL_BUFB, 0, pA1) TL_PFB(TL_BUFB, 1, pB1) TL_PFA(TL_BUFB, 1, pA1)
         asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         TL_BAR
+        TL_LDB(fb0, 0)
+        if (TL_ABL & 1) { TL_LDB(fb1, 1) TL_LDA(0, 4) }
     }
     if (wr == 1) { TL_BAR }                                       // second wave group runs one barrier behind
 #pragma unroll 1
     for (int t = 0; t < nt; ++t) {
         const uint32_t bo = (t & 1) ? TL_BUFB : 0, bn = TL_BUFB - bo;
-        const int t1 = t + 1 < t_last ? t + 1 : t_last, t2 = t + 2 < t_last ? t + 2 : t_last;
+        const int t1 = (TL_ABL & 16) ? 0 : (t + 1 < t_last ? t + 1 : t_last), t2 = (TL_ABL & 16) ? 0 : (t + 2 < t_last ? t + 2 : t_last);     // (16: every DMA re-reads K-tile 0 — L2-hot)
         const char* pA1 = Ab + (long long)t1 * 128;
         const char* pA2 = Ab + (long long)t2 * 128;
         const char* pB2 = Bb + (long long)t2 * 128;
-        /* ph1 */ TL_LDB(fb0, 0) __builtin_amdgcn_sched_barrier(0); TL_LDA(0, 4) TL_PFA(bn, 2, pA1)
-        asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory"); TL_BAR TL_MMA(0, 4, fb0, 0) TL_BAR
-        /* ph2 */ TL_LDB(fb1, 1) TL_PFB(bo, 0, pB2) TL_BAR TL_MMA(0, 4, fb1, 1) TL_BAR
-        /* ph3 */ TL_LDA(1, 4) TL_PFA(bo, 0, pA2) TL_BAR TL_MMA(1, 4, fb1, 1) TL_BAR
-        /* ph4 */ TL_PFB(bo, 1, pB2) TL_BAR TL_MMA(1, 4, fb0, 0) TL_BAR
-        /* ph5 */ TL_LDA(2, 3) TL_PFA(bo, 1, pA2) TL_BAR TL_MMA(2, 3, fb0, 0) TL_BAR
-        /* ph6 */ asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        /* ph1 */ TL_LDA_(0, 4) TL_BAR TL_MMA_(0, 4, fb0, 0) TL_BAR2
+        /* ph2 */ TL_LDB_(fb1, 1) TL_PFB_(bo, 0, pB2) TL_BAR TL_MMA_(0, 4, fb1, 1) TL_BAR2
+        /* ph3 */ TL_LDA_(1, 4) TL_PFA_(bo, 0, pA2) TL_BAR TL_MMA_(1, 4, fb1, 1) TL_BAR2
+        /* ph4 */ TL_PFB_(bo, 1, pB2) if (!(TL_ABL & 2)) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        TL_BAR TL_MMA_(1, 4, fb0, 0) TL_BAR2
+        /* ph5 */ TL_LDA_(2, 3) TL_PFA_(bo, 1, pA2) TL_BAR TL_MMA_(2, 3, fb0, 0) TL_BAR2
+        /* ph6 */
         {
             const int dl = (t & 1) ? -TL_BUFB : TL_BUFB;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) { aRd[ks] += dl; bRd[ks] += dl; }
         }
-        TL_BAR TL_MMA(2, 3, fb1, 1) TL_BAR
+        TL_LDB_(fb0, 0) TL_PFA_(bn, 2, pA1)
+        TL_BAR TL_MMA_(2, 3, fb1, 1) TL_BAR2
     }
     if (wr == 0) { TL_BAR }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // the tail's redundant DMAs drain before the stages are re-used below

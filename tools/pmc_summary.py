@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Summarise two rocprofv3 counter passes (FETCH_SIZE, WRITE_SIZE; collected separately, --pmc + --kernel-trace only)
-into profiles/rNN_pmc_gemm.json (pass the round's name as the 4th argument) for one kernel-name substring.
+into profiles/rNN_pmc_gemm.json (pass the round's name as the 4th argument) for one kernel-name substring (or several, `a|b`: averaged over
+the launches of all of them — the 8-phase GEMM runs as gemm_nt_bf16_8phase_kernel and gemm_nt_bf16_tall_kernel).
 
   python tools/pmc_summary.py <fetch_counter_collection.csv> <write_counter_collection.csv> [kernel substring] [out.json]
 
@@ -12,7 +13,7 @@ import csv, json, sys
 def avg_counter(path, counter, sub):
     tot, n = 0.0, 0
     for r in csv.DictReader(open(path)):
-        if r["Counter_Name"] == counter and sub in r["Kernel_Name"]:
+        if r["Counter_Name"] == counter and any(x in r["Kernel_Name"] for x in sub.split("|")):
             tot += float(r["Counter_Value"])
             n += 1
     return (tot / n if n else 0.0), n
