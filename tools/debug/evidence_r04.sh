@@ -6,7 +6,7 @@ tail -1 gpurun_out/ev/bench_full.log > gpurun_out/ev/r04_c_bench_line.json
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/ev/prof_step -- python3 bench.py --no-extras --no-cpu-baseline > gpurun_out/ev/prof_step.log 2>&1
 cp $(find gpurun_out/ev/prof_step -name "*kernel_stats.csv" | head -1) gpurun_out/ev/r04_d_step_kernel_stats.csv
-tail -1 gpurun_out/ev/prof_step.log > gpurun_out/ev/r04_d_bench_line.json
+grep -h "^{\"metric\"" gpurun_out/ev/prof_step.log > gpurun_out/ev/r04_d_bench_line.json
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/ev/pmc_f -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-extras > gpurun_out/ev/pmc_f.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/ev/pmc_w -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-extras > gpurun_out/ev/pmc_w.log 2>&1
 python3 tools/pmc_summary.py $(find gpurun_out/ev/pmc_f -name "*counter_collection.csv" | head -1) $(find gpurun_out/ev/pmc_w -name "*counter_collection.csv" | head -1) "gemm_nt_bf16_8phase_kernel|gemm_nt_bf16_tall_kernel" gpurun_out/ev/r04_pmc_gemm.json > gpurun_out/ev/pmc_sum.log 2>&1
