@@ -860,9 +860,10 @@ void gemm_nt_bf16_tall_kernel(FastArgs g) {
         int bid = blockIdx.x;
         const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-        const int per_group = 8 * g.tiles_n;
-        const int grp = bid / per_group, first_tm = grp * 8;
-        const int gsz = (g.tiles_m - first_tm) < 8 ? (g.tiles_m - first_tm) : 8;
+        const int gd = g.full_tm;                                     // tile rows per group (launch_tall)
+        const int per_group = gd * g.tiles_n;
+        const int grp = bid / per_group, first_tm = grp * gd;
+        const int gsz = (g.tiles_m - first_tm) < gd ? (g.tiles_m - first_tm) : gd;
         const int in_g = bid - grp * per_group;
         tm = first_tm + in_g % gsz; tn = in_g / gsz;
     }
@@ -1731,6 +1732,9 @@ static bool tall_form(const egomi_gemm_desc* d) {
 static int launch_tall(const egomi_gemm_desc* d, FastArgs& g, hipStream_t s, hipEvent_t t0, hipEvent_t t1) {
     g.tiles_m = (d->M + TL_BM - 1) / TL_BM; g.tiles_n = (d->N + 255) / 256;
     g.splitk = 1; g.ws = nullptr; g.tickets = nullptr; g.epi = 0;
+    static int gdepth = -1;
+    if (gdepth < 0) { const char* e = getenv("EGOMI_TALL_GROUP"); gdepth = e ? atoi(e) : 8; if (gdepth < 1) gdepth = 8; }
+    g.full_tm = gdepth;
     const int nwg = g.tiles_m * g.tiles_n;
     if (t0) (void)hipEventRecord(t0, s);
     if (d->c_dtype == EGOMI_BF16) EGOMI_LAUNCH(gemm_nt_bf16_tall_kernel<bf16_t>, dim3(nwg), dim3(512), 0, s, g);

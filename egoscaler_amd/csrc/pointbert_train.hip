@@ -8,16 +8,44 @@
 #include <math.h>
 
 // ------------------------------------------------------------------------------------------------
+// Fixed-order second stage of every column reduction in this file: out[w] (+)= part[0][w] + part[1][w] + ... + part[P-1][w].
+// The first stages write one partial row per block into the caller's scratch (no fp32 atomics anywhere: round 3's kernels met in
+// dw / db / the batch statistics / dgamma / dbeta / dW with atomicAdd, whose order — and with it the last bits of the train-mode
+// BatchNorm OUTPUT — changed from run to run).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ordered_partial_sum_kernel(const float* part, int P, long long W, float* out, int accumulate) {
+    const long long w = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (w >= W) return;
+    float s = 0.f;
+    for (int p = 0; p < P; ++p) s += part[(long long)p * W + w];
+    out[w] = accumulate ? out[w] + s : s;
+}
+// out[w] += sum over p of part[p * stride + off + w], w < W (a column block of the partial rows)
+__global__ __launch_bounds__(256) void ordered_partial_sum_strided_kernel(const float* part, int P, long long stride, long long off, long long W, float* out) {
+    const long long w = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (w >= W) return;
+    float s = 0.f;
+    for (int p = 0; p < P; ++p) s += part[(long long)p * stride + off + w];
+    out[w] += s;
+}
+static int ordered_partial_sum(const float* part, int P, long long W, float* out, int accumulate, hipStream_t s) {
+    EGOMI_LAUNCH(ordered_partial_sum_kernel, dim3((unsigned)((W + 255) / 256)), dim3(256), 0, s, part, P, W, out, accumulate);
+    return egomi_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------
 // LayerNorm backward: dx = rstd*(g - mean(g) - xh*mean(g*xh)) (+ dx_add), g = w*dy;
-// dw += sum dy*xh, db += sum dy.  One wave per row; per-block partials -> atomics at the end.
+// dw += sum dy*xh, db += sum dy.  One wave per row; every wave keeps its own [2][cols] partial row in LDS (column c of wave v has ONE
+// writer: lane c % 64), the block adds its four rows in wave order into partials[block], ordered_partial_sum_kernel adds the blocks.
 // ------------------------------------------------------------------------------------------------
 template <typename T>
-__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* dy, const T* x, const T* w, T* dx, const T* dx_add, float* dw, float* db,
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* dy, const T* x, const T* w, T* dx, const T* dx_add, float* part,
                                                             int rows, int cols, float eps) {
-    extern __shared__ float sm[];                     // [2][cols] block partials of dw, db
-    for (int c = threadIdx.x; c < 2 * cols; c += 256) sm[c] = 0.f;
+    extern __shared__ float sm[];                     // [4 waves][2][cols]
+    for (int c = threadIdx.x; c < 8 * cols; c += 256) sm[c] = 0.f;
     __syncthreads();
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    float* my = sm + (long long)wv * 2 * cols;
     for (long long row = (long long)blockIdx.x * 4 + wv; row < rows; row += (long long)gridDim.x * 4) {
         const T* xr = x + row * cols;
         const T* gr = dy + row * cols;
@@ -38,24 +66,30 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* dy, const T
             float v = rstd * (g - sg - xh * sgx);
             if (dx_add) v += Cvt<T>::ld(dx_add + row * cols + c);
             Cvt<T>::st(dx + row * cols + c, v);
-            atomicAdd(&sm[c], gy * xh);
-            atomicAdd(&sm[cols + c], gy);
+            my[c] += gy * xh;
+            my[cols + c] += gy;
         }
     }
     __syncthreads();
-    for (int c = threadIdx.x; c < cols; c += 256) {
-        if (dw) atomicAdd(dw + c, sm[c]);
-        if (db) atomicAdd(db + c, sm[cols + c]);
-    }
+    if (part)
+        for (int c = threadIdx.x; c < 2 * cols; c += 256)
+            part[(long long)blockIdx.x * 2 * cols + c] = ((sm[c] + sm[2 * cols + c]) + sm[4 * cols + c]) + sm[6 * cols + c];
 }
 
 extern "C" int egomi_layernorm_bwd(const void* dy, const void* x, const void* w, void* dx, const void* dx_add, float* dw, float* db,
-                                   int rows, int cols, float eps, int dtype, egomi_stream_t stream) {
+                                   int rows, int cols, float eps, float* partials, int64_t partial_floats, int dtype, egomi_stream_t stream) {
     if (!dy || !x || !w || !dx) return EGOMI_E_BADARG;
-    if (rows <= 0 || cols <= 0 || cols > 8192) return EGOMI_E_SHAPE;
+    if (rows <= 0 || cols <= 0 || cols > 2048) return EGOMI_E_SHAPE;
     const int grid = (rows + 3) / 4 < 512 ? (rows + 3) / 4 : 512;
-    EGOMI_DISPATCH_DTYPE(dtype, EGOMI_LAUNCH(layernorm_bwd_kernel<T>, dim3(grid), dim3(256), 2 * cols * sizeof(float), (hipStream_t)stream,
-                                             (const T*)dy, (const T*)x, (const T*)w, (T*)dx, (const T*)dx_add, dw, db, rows, cols, eps));
+    const bool red = dw || db;
+    if (red && (!partials || partial_floats < (int64_t)grid * 2 * cols)) return EGOMI_E_BADARG;
+    hipStream_t s = (hipStream_t)stream;
+    EGOMI_DISPATCH_DTYPE(dtype, EGOMI_LAUNCH(layernorm_bwd_kernel<T>, dim3(grid), dim3(256), 8 * cols * sizeof(float), s,
+                                             (const T*)dy, (const T*)x, (const T*)w, (T*)dx, (const T*)dx_add, red ? partials : nullptr, rows, cols, eps));
+    if (dw && db && db == dw + cols) return ordered_partial_sum(partials, grid, 2ll * cols, dw, 1, s);       // back to back: one pass
+    // dw / db anywhere: a partial row is [dw cols | db cols], so each half is a strided view of it
+    if (dw) { EGOMI_LAUNCH(ordered_partial_sum_strided_kernel, dim3((cols + 255) / 256), dim3(256), 0, s, (const float*)partials, grid, 2ll * cols, 0ll, (long long)cols, dw); }
+    if (db) { EGOMI_LAUNCH(ordered_partial_sum_strided_kernel, dim3((cols + 255) / 256), dim3(256), 0, s, (const float*)partials, grid, 2ll * cols, (long long)cols, (long long)cols, db); }
     return egomi_launch_status();
 }
 
@@ -63,15 +97,15 @@ extern "C" int egomi_layernorm_bwd(const void* dy, const void* x, const void* w,
 // column statistics: sum[c] += sum_r x[r,c], sumsq[c] += sum_r x[r,c]^2  (optionally of x*mask-free)
 // ------------------------------------------------------------------------------------------------
 template <typename T>
-__global__ __launch_bounds__(256) void colstats_kernel(const T* x, long long R, int C, float* sum, float* sumsq, int rows_per_block) {
+__global__ __launch_bounds__(256) void colstats_kernel(const T* x, long long R, int C, float* part /* [gridDim.y][2*C] */, int rows_per_block) {
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= C) return;
     const long long r0 = (long long)blockIdx.y * rows_per_block;
     long long r1 = r0 + rows_per_block; r1 = r1 < R ? r1 : R;
     float a = 0.f, b = 0.f;
     for (long long r = r0; r < r1; ++r) { const float v = Cvt<T>::ld(x + r * C + c); a += v; b += v * v; }
-    atomicAdd(sum + c, a);
-    atomicAdd(sumsq + c, b);
+    part[(long long)blockIdx.y * 2 * C + c] = a;
+    part[(long long)blockIdx.y * 2 * C + C + c] = b;
 }
 
 // y = relu?((x - mean) * rstd * gamma + beta), mean/rstd from the batch sums (biased variance, nn.BatchNorm1d
@@ -102,17 +136,20 @@ __global__ __launch_bounds__(256) void bn_train_apply_kernel(const T* x, long lo
 
 extern "C" int egomi_bn_train_fwd(const void* x, int64_t R, int C, const void* gamma, const void* beta, float eps, int relu, void* y,
                                   float* stats /* [4*C]: sum, sumsq (scratch), mean, rstd (saved) */, void* running_mean, void* running_var,
-                                  float momentum, int dtype, egomi_stream_t stream) {
-    if (!x || !gamma || !beta || !y || !stats) return EGOMI_E_BADARG;
+                                  float momentum, float* partials, int64_t partial_floats, int dtype, egomi_stream_t stream) {
+    if (!x || !gamma || !beta || !y || !stats || !partials) return EGOMI_E_BADARG;
     if (R <= 0 || C <= 0) return EGOMI_E_SHAPE;
     hipStream_t s = (hipStream_t)stream;
-    if (hipMemsetAsync(stats, 0, 2 * (size_t)C * sizeof(float), s) != hipSuccess) return EGOMI_E_LAUNCH;
     const int rpb = 256;
-    dim3 g1((C + 255) / 256, (unsigned)((R + rpb - 1) / rpb));
+    const int nby = (int)((R + rpb - 1) / rpb);
+    if (partial_floats < (int64_t)nby * 2 * C) return EGOMI_E_BADARG;
+    dim3 g1((C + 255) / 256, (unsigned)nby);
     const long long total = R * C;
     const int g2 = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
     EGOMI_DISPATCH_DTYPE(dtype, {
-        EGOMI_LAUNCH(colstats_kernel<T>, g1, dim3(256), 0, s, (const T*)x, (long long)R, C, stats, stats + C, rpb);
+        EGOMI_LAUNCH(colstats_kernel<T>, g1, dim3(256), 0, s, (const T*)x, (long long)R, C, partials, rpb);
+        const int rc = ordered_partial_sum(partials, nby, 2ll * C, stats, 0, s);                 // sum | sumsq, row blocks added in order
+        if (rc != EGOMI_OK) return rc;
         EGOMI_LAUNCH(bn_train_apply_kernel<T>, dim3(g2), dim3(256), 0, s, (const T*)x, (long long)R, C, stats, stats + C, (const T*)gamma, (const T*)beta,
                      eps, relu, (T*)y, stats + 2 * C, stats + 3 * C, (T*)running_mean, (T*)running_var, momentum);
     });
@@ -123,7 +160,7 @@ extern "C" int egomi_bn_train_fwd(const void* x, int64_t R, int C, const void* g
 // dx = gamma*rstd/R * (R*dyr - dbeta - xh*dgamma)
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* dy, const T* x, const T* y, long long R, int C, const float* mean, const float* rstd,
-                                                            int relu, float* dgamma, float* dbeta, int rows_per_block) {
+                                                            int relu, float* part /* [gridDim.y][2*C] */, int rows_per_block) {
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= C) return;
     const long long r0 = (long long)blockIdx.y * rows_per_block;
@@ -136,8 +173,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* dy, const T
         a += g * (Cvt<T>::ld(x + r * C + c) - m) * rs;
         b += g;
     }
-    atomicAdd(dgamma + c, a);
-    atomicAdd(dbeta + c, b);
+    part[(long long)blockIdx.y * 2 * C + c] = a;
+    part[(long long)blockIdx.y * 2 * C + C + c] = b;
 }
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* dy, const T* x, const T* y, long long R, int C, const float* mean, const float* rstd,
@@ -153,19 +190,24 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* dy, const T*
 }
 
 extern "C" int egomi_bn_train_bwd(const void* dy, const void* x, const void* y, int64_t R, int C, const float* stats, const void* gamma, int relu,
-                                  float* dgamma /* [C] zeroed by this call */, float* dbeta, void* dx, int dtype, egomi_stream_t stream) {
-    if (!dy || !x || !y || !stats || !gamma || !dgamma || !dbeta || !dx) return EGOMI_E_BADARG;
+                                  float* dgamma /* [C] written by this call */, float* dbeta, void* dx, float* partials, int64_t partial_floats, int dtype,
+                                  egomi_stream_t stream) {
+    if (!dy || !x || !y || !stats || !gamma || !dgamma || !dbeta || !dx || !partials) return EGOMI_E_BADARG;
     if (R <= 0 || C <= 0) return EGOMI_E_SHAPE;
     hipStream_t s = (hipStream_t)stream;
+    const int rpb = 256;
+    const int nby = (int)((R + rpb - 1) / rpb);
+    if (partial_floats < (int64_t)nby * 2 * C) return EGOMI_E_BADARG;
     if (hipMemsetAsync(dgamma, 0, (size_t)C * sizeof(float), s) != hipSuccess || hipMemsetAsync(dbeta, 0, (size_t)C * sizeof(float), s) != hipSuccess)
         return EGOMI_E_LAUNCH;
-    const int rpb = 256;
-    dim3 g1((C + 255) / 256, (unsigned)((R + rpb - 1) / rpb));
+    dim3 g1((C + 255) / 256, (unsigned)nby);
     const long long total = R * C;
     const int g2 = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
     EGOMI_DISPATCH_DTYPE(dtype, {
         EGOMI_LAUNCH(bn_bwd_reduce_kernel<T>, g1, dim3(256), 0, s, (const T*)dy, (const T*)x, (const T*)y, (long long)R, C, stats + 2 * C, stats + 3 * C, relu,
-                     dgamma, dbeta, rpb);
+                     partials, rpb);
+        EGOMI_LAUNCH(ordered_partial_sum_strided_kernel, dim3((C + 255) / 256), dim3(256), 0, s, (const float*)partials, nby, 2ll * C, 0ll, (long long)C, dgamma);
+        EGOMI_LAUNCH(ordered_partial_sum_strided_kernel, dim3((C + 255) / 256), dim3(256), 0, s, (const float*)partials, nby, 2ll * C, (long long)C, (long long)C, dbeta);
         EGOMI_LAUNCH(bn_bwd_apply_kernel<T>, dim3(g2), dim3(256), 0, s, (const T*)dy, (const T*)x, (const T*)y, (long long)R, C, stats + 2 * C, stats + 3 * C,
                      (const T*)gamma, relu, dgamma, dbeta, (T*)dx);
     });
@@ -218,7 +260,7 @@ extern "C" int egomi_group_max_bwd(const void* dout, const int32_t* idx, int BG,
 // small-K weight gradient: dW[n,k] += sum_r dy[r,n] * x[r,k]   (K <= 8; x may be fp32)
 // ------------------------------------------------------------------------------------------------
 template <typename TX, typename T>
-__global__ __launch_bounds__(256) void smallk_wgrad_kernel(const T* dy, const TX* x, long long R, int N, int K, float* dW, int rows_per_block) {
+__global__ __launch_bounds__(256) void smallk_wgrad_kernel(const T* dy, const TX* x, long long R, int N, int K, float* part /* [gridDim.y][N*K] */, int rows_per_block) {
     const int n = blockIdx.x * 256 + threadIdx.x;
     if (n >= N) return;
     const long long r0 = (long long)blockIdx.y * rows_per_block;
@@ -228,19 +270,22 @@ __global__ __launch_bounds__(256) void smallk_wgrad_kernel(const T* dy, const TX
         const float g = Cvt<T>::ld(dy + r * N + n);
         for (int k = 0; k < K; ++k) acc[k] += g * Cvt<TX>::ld(x + r * K + k);
     }
-    for (int k = 0; k < K; ++k) atomicAdd(dW + (long long)n * K + k, acc[k]);
+    for (int k = 0; k < K; ++k) part[(long long)blockIdx.y * N * K + (long long)n * K + k] = acc[k];
 }
-extern "C" int egomi_smallk_wgrad(const void* dy, const void* x, int x_dtype, int64_t R, int N, int K, float* dW, int dtype, egomi_stream_t stream) {
-    if (!dy || !x || !dW) return EGOMI_E_BADARG;
+extern "C" int egomi_smallk_wgrad(const void* dy, const void* x, int x_dtype, int64_t R, int N, int K, float* dW, float* partials, int64_t partial_floats,
+                                  int dtype, egomi_stream_t stream) {
+    if (!dy || !x || !dW || !partials) return EGOMI_E_BADARG;
     if (R <= 0 || N <= 0 || K <= 0 || K > 8) return EGOMI_E_SHAPE;
     const int rpb = 512;
-    dim3 g((N + 255) / 256, (unsigned)((R + rpb - 1) / rpb));
+    const int nby = (int)((R + rpb - 1) / rpb);
+    if (partial_floats < (int64_t)nby * N * K) return EGOMI_E_BADARG;
+    dim3 g((N + 255) / 256, (unsigned)nby);
     hipStream_t s = (hipStream_t)stream;
-    if (x_dtype == EGOMI_F32 && dtype == EGOMI_F32) EGOMI_LAUNCH((smallk_wgrad_kernel<float, float>), g, dim3(256), 0, s, (const float*)dy, (const float*)x, (long long)R, N, K, dW, rpb);
-    else if (x_dtype == EGOMI_F32 && dtype == EGOMI_BF16) EGOMI_LAUNCH((smallk_wgrad_kernel<float, bf16_t>), g, dim3(256), 0, s, (const bf16_t*)dy, (const float*)x, (long long)R, N, K, dW, rpb);
-    else if (x_dtype == EGOMI_BF16 && dtype == EGOMI_BF16) EGOMI_LAUNCH((smallk_wgrad_kernel<bf16_t, bf16_t>), g, dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)x, (long long)R, N, K, dW, rpb);
+    if (x_dtype == EGOMI_F32 && dtype == EGOMI_F32) EGOMI_LAUNCH((smallk_wgrad_kernel<float, float>), g, dim3(256), 0, s, (const float*)dy, (const float*)x, (long long)R, N, K, partials, rpb);
+    else if (x_dtype == EGOMI_F32 && dtype == EGOMI_BF16) EGOMI_LAUNCH((smallk_wgrad_kernel<float, bf16_t>), g, dim3(256), 0, s, (const bf16_t*)dy, (const float*)x, (long long)R, N, K, partials, rpb);
+    else if (x_dtype == EGOMI_BF16 && dtype == EGOMI_BF16) EGOMI_LAUNCH((smallk_wgrad_kernel<bf16_t, bf16_t>), g, dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)x, (long long)R, N, K, partials, rpb);
     else return EGOMI_E_BADARG;
-    return egomi_launch_status();
+    return ordered_partial_sum(partials, nby, (long long)N * K, dW, 1, s);
 }
 
 // ------------------------------------------------------------------------------------------------

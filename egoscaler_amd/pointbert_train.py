@@ -16,26 +16,43 @@ from .ops import P, S, dt
 PRE = "model.point_backbone."
 
 
+_PART = {}
+
+
+def _partials(n, device):
+    """fp32 scratch for the ordered two-stage column reductions (include/egomi.h): grow-only, one per device; every user runs on the
+    current stream, so consecutive calls may share it."""
+    t = _PART.get(device)
+    if t is None or t.numel() < n:
+        t = torch.empty(max(n, 1 << 20), dtype=torch.float32, device=device)
+        _PART[device] = t
+    return t
+
+
 def layernorm_bwd(dy, x, w, eps, dx_add=None, dw=None, db=None, out=None):
     rows, cols = x.numel() // x.shape[-1], x.shape[-1]
     out = torch.empty_like(x) if out is None else out
-    call("egomi_layernorm_bwd", P(dy), P(x), P(w), P(out), P(dx_add), P(dw), P(db), c_i(rows), c_i(cols), c_f(eps), c_i(dt(x.dtype)), S())
+    pt = _partials(min((rows + 3) // 4, 512) * 2 * cols, x.device)
+    call("egomi_layernorm_bwd", P(dy), P(x), P(w), P(out), P(dx_add), P(dw), P(db), c_i(rows), c_i(cols), c_f(eps), P(pt), c_i64(pt.numel()),
+         c_i(dt(x.dtype)), S())
     return out
 
 
 def bn_train_fwd(x, gamma, beta, eps, relu, stats, rmean, rvar, momentum=0.1, out=None):
     R, C = x.shape
     out = torch.empty_like(x) if out is None else out
+    pt = _partials((R + 255) // 256 * 2 * C, x.device)
     call("egomi_bn_train_fwd", P(x), c_i64(R), c_i(C), P(gamma), P(beta), c_f(eps), c_i(int(relu)), P(out), P(stats), P(rmean), P(rvar),
-         c_f(momentum), c_i(dt(x.dtype)), S())
+         c_f(momentum), P(pt), c_i64(pt.numel()), c_i(dt(x.dtype)), S())
     return out
 
 
 def bn_train_bwd(dy, x, y, stats, gamma, relu, dgamma, dbeta, out=None):
     R, C = x.shape
     out = torch.empty_like(x) if out is None else out
+    pt = _partials((R + 255) // 256 * 2 * C, x.device)
     call("egomi_bn_train_bwd", P(dy), P(x), P(y), c_i64(R), c_i(C), P(stats), P(gamma), c_i(int(relu)), P(dgamma), P(dbeta), P(out),
-         c_i(dt(x.dtype)), S())
+         P(pt), c_i64(pt.numel()), c_i(dt(x.dtype)), S())
     return out
 
 
@@ -54,7 +71,8 @@ def group_max_bwd(dout, idx, BG, M, C, dx, accumulate):
 def smallk_wgrad(dy, x, dW):
     R, N = dy.shape
     K = x.shape[-1]
-    call("egomi_smallk_wgrad", P(dy), P(x), c_i(dt(x.dtype)), c_i64(R), c_i(N), c_i(K), P(dW), c_i(dt(dy.dtype)), S())
+    pt = _partials((R + 511) // 512 * N * K, dy.device)
+    call("egomi_smallk_wgrad", P(dy), P(x), c_i(dt(x.dtype)), c_i64(R), c_i(N), c_i(K), P(dW), P(pt), c_i64(pt.numel()), c_i(dt(dy.dtype)), S())
 
 
 def rowscale_add(resid, branch, scale, rows_per_sample, out=None):

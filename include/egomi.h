@@ -303,22 +303,30 @@ int egomi_traj_metrics(const float* gen, const int32_t* n_gen, const float* gt, 
  *   bn_train_fwd  : y = relu?(BatchNorm1d(x)) with BATCH statistics over the R rows (biased variance),
  *                   running stats updated with `momentum` (unbiased variance), stats = fp32 [4*C]
  *                   scratch/saved block {sum, sumsq, mean, rstd}
- *   bn_train_bwd  : dx, dgamma, dbeta (fp32 [C], zeroed by the call) from dy, x, y and the saved stats
+ *   bn_train_bwd  : dx, dgamma, dbeta (fp32 [C], written by the call) from dy, x, y and the saved stats
  *   group_argmax  : x [BG,M,C] -> max over M and its first arg-max;  group_max_bwd scatters dout back
  *   smallk_wgrad  : dW[n,k] (fp32, caller-zeroed/accumulating) += sum_r dy[r,n]*x[r,k], K <= 8
  *   group_sum     : out[bg,c] = sum_m x[(bg*M+m)*ldx + c]  (backward of the expanded group-global feature)
  *   rowscale_add  : out[r,:] = resid[r,:] + scale[r / rows_per_sample] * branch[r,:]   (DropPath)
+ * Column reductions (dw / db, the batch statistics, dgamma / dbeta, dW) are two-stage and ORDERED — one partial row per block in the caller's
+ * fp32 scratch `partials`, added in block order by a second kernel; no atomics, the same bits every run (the batch statistics feed the
+ * forward output, so this makes the train-mode backbone's forward replayable too).  `partial_floats` must be at least
+ *   layernorm_bwd (dw or db given): min(ceil(rows / 4), 512) * 2 * cols        bn_train_fwd / bn_train_bwd: ceil(R / 256) * 2 * C
+ *   smallk_wgrad: ceil(R / 512) * N * K
+ * (EGOMI_E_BADARG otherwise); cols <= 2048 for layernorm_bwd.
  */
 int egomi_layernorm_bwd(const void* dy, const void* x, const void* w, void* dx, const void* dx_add, float* dw, float* db,
-                        int rows, int cols, float eps, int dtype, egomi_stream_t stream);
+                        int rows, int cols, float eps, float* partials, int64_t partial_floats, int dtype, egomi_stream_t stream);
 int egomi_bn_train_fwd(const void* x, int64_t R, int C, const void* gamma, const void* beta, float eps, int relu, void* y,
-                       float* stats, void* running_mean, void* running_var, float momentum, int dtype, egomi_stream_t stream);
+                       float* stats, void* running_mean, void* running_var, float momentum, float* partials, int64_t partial_floats, int dtype,
+                       egomi_stream_t stream);
 int egomi_bn_train_bwd(const void* dy, const void* x, const void* y, int64_t R, int C, const float* stats, const void* gamma, int relu,
-                       float* dgamma, float* dbeta, void* dx, int dtype, egomi_stream_t stream);
+                       float* dgamma, float* dbeta, void* dx, float* partials, int64_t partial_floats, int dtype, egomi_stream_t stream);
 int egomi_group_argmax(const void* x, int BG, int M, int C, void* out, int32_t* idx, int dtype, egomi_stream_t stream);
 int egomi_group_max_bwd(const void* dout, const int32_t* idx, int BG, int M, int C, void* dx, int64_t ldx, int accumulate, int dtype,
                         egomi_stream_t stream);
-int egomi_smallk_wgrad(const void* dy, const void* x, int x_dtype, int64_t R, int N, int K, float* dW, int dtype, egomi_stream_t stream);
+int egomi_smallk_wgrad(const void* dy, const void* x, int x_dtype, int64_t R, int N, int K, float* dW, float* partials, int64_t partial_floats, int dtype,
+                       egomi_stream_t stream);
 int egomi_group_sum(const void* x, int BG, int M, int C, int64_t ldx, void* out, int dtype, egomi_stream_t stream);
 int egomi_rowscale_add(const void* resid, const void* branch, const float* scale, int64_t rows, int cols, int rows_per_sample, void* out,
                        int dtype, egomi_stream_t stream);

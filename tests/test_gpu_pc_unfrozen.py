@@ -179,3 +179,33 @@ def test_point_backbone_with_96_wide_heads_matches_oracle():
         lg = m(input_ids=toks.cuda(), attention_mask=masks.cuda(), point_clouds=pts.cuda(), fps_start=[0, 17]).logits
         ref = OPL.forward({k: v.clone() for k, v in sd.items()}, dims, toks, masks, pts, np.array([0, 17]))
     assert rel(lg, ref.numpy()) < REL
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_unfrozen_point_backbone_step_is_replayable_bit_for_bit(dtype):
+    """Two fresh models, the same batch: loss, every gradient (the point backbone's included) and the BatchNorm running statistics are the
+    SAME BITS.  The column reductions of csrc/pointbert_train.hip (LayerNorm dw / db, train-mode BatchNorm batch statistics and dgamma /
+    dbeta, the small-K weight gradients) are ordered two-stage sums since round 4; before, fp32 atomics made even the forward differ in
+    its last bits (the batch statistics).  DropPath off (its masks are fresh draws)."""
+    dims = dims_tiny()
+    dims.pb.drop_path_rate = 0.0
+    B = 4
+    toks, masks, Lp = synth.synth_batch(dims, B, text_len=8, num_steps=4, max_traj_token=40)
+    pts = torch.stack([synth.synth_cloud(dims, i) for i in range(B)])
+    start = torch.zeros(B, dtype=torch.int32)
+    runs = []
+    for _ in range(2):
+        m = _model(dims, dtype)
+        m.train()
+        loss = m.loss_and_backward(toks.cuda(), masks.cuda(), pts.cuda(), Lp, dims.tok.pad, fps_start=start.cuda())
+        torch.cuda.synchronize()
+        grads = {n: p.main_grad.clone() for n, p in m.named_parameters() if getattr(p, "main_grad", None) is not None}
+        stats = {k: v.clone() for k, v in m.state_dict().items() if "running_" in k}
+        runs.append((float(loss), grads, stats))
+        del m
+    assert runs[0][0] == runs[1][0]
+    assert any(n.startswith("model.point_backbone.") for n in runs[0][1])
+    for n in runs[0][1]:
+        assert torch.equal(runs[0][1][n], runs[1][1][n]), n
+    for k in runs[0][2]:
+        assert torch.equal(runs[0][2][k], runs[1][2][k]), k
