@@ -1034,13 +1034,71 @@ void gemm_nt_bf16_tall_kernel(FastArgs g) {
             }
             return;
         }
+        if (g.epi == 3) {
+            // SwiGLU backward in the epilogue of the down_proj data gradient (the 256x256 form's epilogue, same arithmetic and rounding sequence):
+            // sub-passes of 32 rows = 2 row blocks (the sixth has one), gate|up rows in as 256-B segments into a wave-private strip (272-B pitch),
+            // combined in place, out as 256-B segments.  d(act) never reaches memory.
+            char* ws3 = smem + wave * (32 * 272);
+            const bf16_t* GU = reinterpret_cast<const bf16_t*>(g.C2);
+            const int lr = lane >> 4, ch = lane & 15;
+            u32x4 in[8];
+#define TL_GU_FETCH(sp_) _Pragma("unroll") for (int it = 0; it < 8; ++it) { \
+                    if ((sp_) * 32 + it * 4 >= 16 * TL_NB) continue; \
+                    int m_ = mb + (sp_) * 32 + it * 4 + lr; \
+                    m_ = m_ < g.M ? m_ : g.M - 1; \
+                    in[it] = *reinterpret_cast<const u32x4*>(GU + (long long)m_ * g.ldc2 + 2 * nb + ch * 8); }
+            TL_GU_FETCH(0)
+#pragma unroll
+            for (int sp = 0; sp < (TL_NB + 1) / 2; ++sp) {
+#pragma unroll
+                for (int it = 0; it < 8; ++it) {
+                    if (sp * 32 + it * 4 >= 16 * TL_NB) continue;
+                    *reinterpret_cast<u32x4*>(ws3 + (it * 4 + lr) * 272 + ch * 16) = in[it];
+                }
+                if (sp + 1 < (TL_NB + 1) / 2) { TL_GU_FETCH(sp + 1) }
+#pragma unroll
+                for (int i2 = 0; i2 < 2; ++i2) {
+                    if (2 * sp + i2 >= TL_NB) continue;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const f32x4 v = acc[j][2 * sp + i2];
+                        char* pg = ws3 + (i2 * 16 + (lane & 15)) * 272 + ((j >> 1) * 64 + (j & 1) * 16 + lr * 4) * 2;
+                        const u32x2 gg = *reinterpret_cast<const u32x2*>(pg), uu = *reinterpret_cast<const u32x2*>(pg + 64);
+                        float og[4], ou[4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float gv = __uint_as_float((r & 1) ? (gg[r >> 1] & 0xFFFF0000u) : (gg[r >> 1] << 16));
+                            const float uv = __uint_as_float((r & 1) ? (uu[r >> 1] & 0xFFFF0000u) : (uu[r >> 1] << 16));
+                            swiglu_bwd_elem(bf2f(f2bf(v[r])), gv, uv, og[r], ou[r]);
+                        }
+                        u32x2 o;
+                        o[0] = (uint32_t)f2bf(og[0]) | ((uint32_t)f2bf(og[1]) << 16);
+                        o[1] = (uint32_t)f2bf(og[2]) | ((uint32_t)f2bf(og[3]) << 16);
+                        *reinterpret_cast<u32x2*>(pg) = o;
+                        o[0] = (uint32_t)f2bf(ou[0]) | ((uint32_t)f2bf(ou[1]) << 16);
+                        o[1] = (uint32_t)f2bf(ou[2]) | ((uint32_t)f2bf(ou[3]) << 16);
+                        *reinterpret_cast<u32x2*>(pg + 64) = o;
+                    }
+                }
+#pragma unroll
+                for (int it = 0; it < 8; ++it) {
+                    if (sp * 32 + it * 4 >= 16 * TL_NB) continue;
+                    const int m = mb + sp * 32 + it * 4 + lr;
+                    const u32x4 v = *reinterpret_cast<const u32x4*>(ws3 + (it * 4 + lr) * 272 + ch * 16);
+                    if (m < g.M) *reinterpret_cast<u32x4*>(C + (long long)m * g.ldc + 2 * nb + ch * 8) = v;
+                }
+            }
+#undef TL_GU_FETCH
+            return;
+        }
         // plain bf16 store through a wave-private LDS strip (64 rows x 144-B pitch) as 128-B row segments, as the 256x256 kernel
         char* wb = smem + wave * (64 * 144);
 #pragma unroll
         for (int pass = 0; pass < 3; ++pass) {
+            const int nblk = (TL_NB - 4 * pass) < 4 ? (TL_NB - 4 * pass) : 4;
 #pragma unroll
             for (int ii = 0; ii < 4; ++ii) {
-                if (4 * pass + ii >= TL_NB) continue;
+                if (ii >= nblk) continue;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const f32x4 v = acc[j][4 * pass + ii];
@@ -1053,10 +1111,42 @@ void gemm_nt_bf16_tall_kernel(FastArgs g) {
 #pragma unroll
             for (int it = 0; it < 8; ++it) {
                 const int r = it * 8 + (lane >> 3), ch = lane & 7;
-                if (4 * pass * 16 + it * 8 >= 16 * TL_NB) continue;
+                if (it * 8 >= nblk * 16) continue;
                 const u32x4 v = *reinterpret_cast<const u32x4*>(wb + r * 144 + ch * 16);
                 const int m = mb + pass * 64 + r;
                 if (m < g.M) *reinterpret_cast<u32x4*>(C + (long long)m * g.ldc + nb + ch * 8) = v;
+            }
+            if (g.epi == 1) {
+                // SwiGLU in the epilogue (the 256x256 form's, same rounding sequence): the wave's 64 columns are one interleaved-32 group, gate in
+                // accumulators j = 0,1 and up of the same 32 hidden units in j = 2,3; act rows leave as 64-B segments through the same strip
+                bf16_t* C2 = reinterpret_cast<bf16_t*>(g.C2);
+#pragma unroll
+                for (int ii = 0; ii < 4; ++ii) {
+                    if (ii >= nblk) continue;
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const f32x4 vg = acc[j][4 * pass + ii], vu = acc[j + 2][4 * pass + ii];
+                        float o4[4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float gg = bf2f(f2bf(vg[r])), uu = bf2f(f2bf(vu[r]));
+                            const float a = bf2f(f2bf(gg * (1.0f / (1.0f + __expf(-gg)))));
+                            o4[r] = a * uu;
+                        }
+                        u32x2 o;
+                        o[0] = (uint32_t)f2bf(o4[0]) | ((uint32_t)f2bf(o4[1]) << 16);
+                        o[1] = (uint32_t)f2bf(o4[2]) | ((uint32_t)f2bf(o4[3]) << 16);
+                        *reinterpret_cast<u32x2*>(wb + (ii * 16 + (lane & 15)) * 144 + (j * 16 + (lane >> 4) * 4) * 2) = o;
+                    }
+                }
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    if (it * 16 >= nblk * 16) continue;
+                    const int r = it * 16 + (lane >> 2), ch = lane & 3;
+                    const u32x4 v = *reinterpret_cast<const u32x4*>(wb + r * 144 + ch * 16);
+                    const int m = mb + pass * 64 + r;
+                    if (m < g.M) *reinterpret_cast<u32x4*>(C2 + (long long)m * g.ldc2 + (nb >> 1) + ch * 8) = v;
+                }
             }
         }
         return;
@@ -1716,7 +1806,7 @@ static bool tall_form(const egomi_gemm_desc* d) {
     if (g_tall_mode < 0) { const char* e = getenv("EGOMI_GEMM_TALL"); g_tall_mode = e ? atoi(e) : 1; if (g_tall_mode < 0 || g_tall_mode > 2) g_tall_mode = 1; }
     const int mode = g_tall_mode;
     if (!mode) return false;
-    if (d->epilogue != EGOMI_EPI_NONE && d->epilogue != EGOMI_EPI_SLABS) return false;
+    if (d->epilogue != EGOMI_EPI_NONE && d->epilogue != EGOMI_EPI_SLABS && d->epilogue != EGOMI_EPI_SWIGLU && d->epilogue != EGOMI_EPI_SWIGLU_BWD) return false;
     if ((d->M & 7) || (d->N & 7) || d->M < TL_BM || d->N < 256 || d->K < 2048 || d->split_k > 1) return false;      // (split_k = 1: "no K-sliced rows", the tests' way to compare whole tiles of both forms)
     if ((long long)d->M * d->lda >= (1ll << 31) || (long long)d->N * d->ldb >= (1ll << 31)) return false;
     if (d->c_dtype != EGOMI_BF16 && d->c_dtype != EGOMI_F32) return false;
@@ -1731,7 +1821,8 @@ static bool tall_form(const egomi_gemm_desc* d) {
 }
 static int launch_tall(const egomi_gemm_desc* d, FastArgs& g, hipStream_t s, hipEvent_t t0, hipEvent_t t1) {
     g.tiles_m = (d->M + TL_BM - 1) / TL_BM; g.tiles_n = (d->N + 255) / 256;
-    g.splitk = 1; g.ws = nullptr; g.tickets = nullptr; g.epi = 0;
+    g.splitk = 1; g.ws = nullptr; g.tickets = nullptr;
+    if (g.epi == EGOMI_EPI_SLABS) g.epi = 0;                          // (a product in this form has no K-sliced rows to leave as slabs)
     static int gdepth = -1;
     if (gdepth < 0) { const char* e = getenv("EGOMI_TALL_GROUP"); gdepth = e ? atoi(e) : 8; if (gdepth < 1) gdepth = 8; }
     g.full_tm = gdepth;
@@ -1835,6 +1926,57 @@ static int launch_8phase(const egomi_gemm_desc* d, FastArgs& g, hipStream_t s, i
     return egomi_launch_status();
 }
 
+// ---- column split: the 352x256 form on the first Na columns (whole rounds), the 256x256 form on the rest.  Products whose tiles fit neither
+// form in whole rounds: gate|up at M = 5536 (N = 22016: 1892 tiles of 256x256 = 7.39 rounds; 16 x 86 tall tiles = 5.375) runs as 16 x 64 tall tiles
+// (4 rounds) + 22 x 22 tiles of 256x256 (1.89 rounds), the down_proj data gradient (N = 11008: 3.70 / 2.69 rounds) as 16 x 32 tall (2 rounds) +
+// 22 x 11 (0.95 rounds).  Same round model as tall_form(); both parts carry the product's epilogue (plain, SwiGLU, SwiGLU backward); the second
+// part plans its own K-sliced tail.  Na is a multiple of 256 columns, so interleaved-32 gate|up groups and 64-column wave strips stay whole.
+static double c256_model(long long tiles, bool ws) {
+    const int ncu = 256;
+    const int rem = (int)(tiles % ncu);
+    return (double)(tiles / ncu) + (rem ? (rem * 2 <= ncu && ws ? 0.28 + 0.85 * rem / ncu : 1.0) : 0.0);
+}
+static int split_cols(const egomi_gemm_desc* d) {
+    if (g_tall_mode < 0) { const char* e = getenv("EGOMI_GEMM_TALL"); g_tall_mode = e ? atoi(e) : 1; if (g_tall_mode < 0 || g_tall_mode > 2) g_tall_mode = 1; }
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("EGOMI_GEMM_SPLIT"); on = e ? atoi(e) : 1; }
+    if (g_tall_mode != 1 || !on) return 0;                             // (mode 2 = "the tall form wherever it applies" is the whole-product A/B arm)
+    if (d->epilogue != EGOMI_EPI_NONE && d->epilogue != EGOMI_EPI_SWIGLU && d->epilogue != EGOMI_EPI_SWIGLU_BWD) return 0;
+    if ((d->M & 7) || (d->N & 255) || d->M < TL_BM || d->K < 2048 || d->split_k > 0 || d->bias) return 0;
+    if ((long long)d->M * d->lda >= (1ll << 31) || (long long)d->N * d->ldb >= (1ll << 31)) return 0;
+    if (d->c_dtype != EGOMI_BF16 && d->c_dtype != EGOMI_F32) return 0;
+    const int ncu = 256;
+    const long long tn = d->N / 256, tm256 = (d->M + 255) / 256, tm352 = (d->M + TL_BM - 1) / TL_BM;
+    const double c0 = c256_model(tm256 * tn, d->workspace != nullptr);
+    double best = 0.97 * c0;
+    int ja_best = 0;
+    for (long long ja = 1; ja < tn; ++ja) {
+        if ((tm352 * ja) % ncu) continue;                                // the tall part: whole rounds only
+        const double c = 1.31 * (double)(tm352 * ja / ncu) + c256_model(tm256 * (tn - ja), d->workspace != nullptr) + 0.03;
+        if (c < best) { best = c; ja_best = (int)ja; }
+    }
+    return ja_best * 256;
+}
+static int launch_split(const egomi_gemm_desc* d, const FastArgs& g, int Na, hipStream_t s, hipEvent_t t0, hipEvent_t t1) {
+    const int esz = d->c_dtype == EGOMI_BF16 ? 2 : 4;
+    egomi_gemm_desc d1 = *d;
+    d1.N = Na;
+    FastArgs g1 = g;
+    g1.N = Na;
+    int rc = launch_tall(&d1, g1, s, t0, nullptr);
+    if (rc != EGOMI_OK) return rc;
+    egomi_gemm_desc d2 = *d;
+    FastArgs g2 = g;
+    d2.N = g2.N = d->N - Na;
+    d2.B = g2.B = (const bf16_t*)d->B + (long long)Na * d->ldb;
+    const long long ccol = d->epilogue == EGOMI_EPI_SWIGLU_BWD ? 2ll * Na : (long long)Na;       // C is d(gate|up) [M, 2N] there
+    d2.C = g2.C = (char*)d->C + ccol * esz;
+    if (d->residual) d2.residual = g2.residual = (const char*)d->residual + (long long)Na * esz;
+    if (d->epilogue == EGOMI_EPI_SWIGLU) d2.C2 = g2.C2 = (char*)d->C2 + (long long)(Na / 2) * 2;   // act [M, N/2]
+    if (d->epilogue == EGOMI_EPI_SWIGLU_BWD) d2.C2 = g2.C2 = (char*)d->C2 + 2ll * Na * 2;          // gate|up [M, 2N]
+    return launch_8phase(&d2, g2, s, nullptr, nullptr, t1);
+}
+
 // returns 0 on success, <0 on error, 1 when the tuned kernel does not apply
 // EGOMI_EPI_SLABS (include/egomi.h): plain product only — everything an epilogue could do is the consumer kernel's job
 static bool slabs_form_ok(const egomi_gemm_desc* d) {
@@ -1855,7 +1997,7 @@ int egomi_gemm_fast_try(const egomi_gemm_desc* d0, hipStream_t s) {
     g.alpha = d->alpha; g.accumulate = d->accumulate; g.act = d->act; g.tickets = nullptr;
     g.epi = d->epilogue; g.C2 = d->C2; g.ldc2 = d->ldc2;
     const int tc = tile_choice(d);
-    if (tc == 8 && tall_form(d)) {
+    if (tc == 8 && (d->epilogue == EGOMI_EPI_NONE || d->epilogue == EGOMI_EPI_SLABS) && tall_form(d)) {
         if (d->epilogue == EGOMI_EPI_SLABS && (d->bias || d->accumulate || d->act != 0 || d->alpha != 1.0f || d->c_dtype != EGOMI_BF16)) return EGOMI_E_UNSUPPORTED;
         return launch_tall(d, g, s, t0, t1);
     }
@@ -1893,6 +2035,8 @@ int egomi_gemm_fast_try(const egomi_gemm_desc* d0, hipStream_t s) {
             if (dl.workspace_bytes > 4096) { dl.workspace = (char*)dl.workspace + 4096; dl.workspace_bytes -= 4096; }
             else { dl.workspace = nullptr; dl.workspace_bytes = 0; }
         }
+        if (tall_form(d)) return launch_tall(d, g, s, t0, t1);              // the fused epilogues live in both forms
+        if (const int Na = split_cols(d)) return launch_split(d, g, Na, s, t0, t1);
         return launch_8phase(d, g, s, nullptr, t0, t1);
     }
     if (tc == 8 && (long long)d->M * d->lda < (1ll << 31) && (long long)d->N * d->ldb < (1ll << 31)) {
@@ -1913,6 +2057,9 @@ int egomi_gemm_fast_try(const egomi_gemm_desc* d0, hipStream_t s) {
     static int fold = -1;
     if (fold < 0) { const char* e = getenv("EGOMI_GEMM_FOLD"); fold = e ? atoi(e) : 0; }
     if (!fold && dl.ws_tickets_zeroed != 2) tickets = nullptr;
-    if (tc == 8 && (long long)d->M * d->lda < (1ll << 31) && (long long)d->N * d->ldb < (1ll << 31)) return launch_8phase(d, g, s, tickets, t0, t1);
+    if (tc == 8 && (long long)d->M * d->lda < (1ll << 31) && (long long)d->N * d->ldb < (1ll << 31)) {
+        if (const int Na = split_cols(d)) return launch_split(d, g, Na, s, t0, t1);
+        return launch_8phase(d, g, s, tickets, t0, t1);
+    }
     return tc == 2 ? launch_fast<256, 128>(d, g, s) : launch_fast<128, 128>(d, g, s);
 }

@@ -490,8 +490,9 @@ def test_swiglu_interleaved32_layout(ops):
     assert torch.equal(dgu, _interleave32(dg, du))
 
 
+@pytest.mark.parametrize("tall_mode", [0, 1, 2])
 @pytest.mark.parametrize("M,Fd,K", [(5536, 11008, 4096), (5000, 2048, 2048), (2304, 8192, 2112)])
-def test_gemm_swiglu_epilogue(ops, M, Fd, K):
+def test_gemm_swiglu_epilogue(ops, M, Fd, K, tall_mode, request):
     """EGOMI_EPI_SWIGLU: x . [Wgate;Wup]^T with the stacked rows interleaved in blocks of 32 — C (gate|up, interleaved-32) equals
     the plain product and C2 equals egomi_swiglu_il_fwd(C) bit for bit, on whole tiles, ragged M and K-sliced tail rows; shapes
     the fused path cannot serve are refused, never silently computed without C2."""
@@ -501,13 +502,11 @@ def test_gemm_swiglu_epilogue(ops, M, Fd, K):
     wg, wu = rnd(Fd, K, dtype=torch.bfloat16, seed=52, scale=0.05).cuda(), rnd(Fd, K, dtype=torch.bfloat16, seed=53, scale=0.05).cuda()
     w = torch.stack([wg.view(Fd // 32, 32, K), wu.view(Fd // 32, 32, K)], 1).reshape(2 * Fd, K).contiguous()
     assert ops.gemm_kernel_id(M, 2 * Fd, K) == 2
-    # the fused epilogue lives in the 256x256 form: the plain reference product takes that form too (same K-sliced tail rows, same bits);
-    # the 352x256 form would sum those rows' K-tiles in one run
-    _lib.lib().egomi_gemm_set_tall(ctypes.c_int(0))
-    try:
-        gu_ref = ops.mm(x, w)
-    finally:
-        _lib.lib().egomi_gemm_set_tall(ctypes.c_int(-1))
+    # (the plain product and the fused one take the same form and the same K-sliced rows in every mode: 0 = 256x256 tiles only, 1 = the library's
+    #  choice — 352x256 tiles, or both forms side by side on a column split —, 2 = 352x256 tiles wherever they apply)
+    _lib.lib().egomi_gemm_set_tall(ctypes.c_int(tall_mode))
+    request.addfinalizer(lambda: _lib.lib().egomi_gemm_set_tall(ctypes.c_int(-1)))
+    gu_ref = ops.mm(x, w)
     act_ref = ops.swiglu_il(gu_ref, torch.empty(M, Fd, dtype=torch.bfloat16, device="cuda"))
     gu = torch.empty_like(gu_ref)
     act = torch.full((M, Fd), 7.0, dtype=torch.bfloat16, device="cuda")
@@ -522,13 +521,17 @@ def test_gemm_swiglu_epilogue(ops, M, Fd, K):
         ops.mm(x, w, out=gu, swiglu_out=act, bias=torch.zeros(2 * Fd, dtype=torch.bfloat16, device="cuda"))
 
 
-@pytest.mark.parametrize("M,Fd,K", [(5536, 11008, 4096), (4500, 2880, 2048), (2304, 4096, 2112), (4100, 4160, 2048)])
-def test_gemm_swiglu_backward_epilogue(ops, M, Fd, K):
+@pytest.mark.parametrize("tall_mode", [0, 1, 2])
+@pytest.mark.parametrize("M,Fd,K", [(5536, 11008, 4096), (4500, 2880, 2048), (2304, 4096, 2112), (4100, 4160, 2048), (5536, 4096, 2048)])
+def test_gemm_swiglu_backward_epilogue(ops, M, Fd, K, tall_mode, request):
     """EGOMI_EPI_SWIGLU_BWD: the down_proj data gradient dx . W_down with SwiGLU's backward in its epilogue — d(gate|up) equals
     egomi_swiglu_il_bwd applied to the stored bf16 product, bit for bit (whole tiles, ragged M, a last column tile that is partly outside
     (Fd % 256 != 0), K-sliced tail rows), d(act) is never written, and it is the right function of the operands; refused where the
     256x256 kernel does not run."""
     from egoscaler_amd import _lib
+    import ctypes
+    _lib.lib().egomi_gemm_set_tall(ctypes.c_int(tall_mode))             # 0 = 256x256 tiles only, 1 = the library's choice (incl. the column split), 2 = 352x256 wherever possible
+    request.addfinalizer(lambda: _lib.lib().egomi_gemm_set_tall(ctypes.c_int(-1)))
     dx = rnd(M, K, dtype=torch.bfloat16, seed=61).cuda()
     wt = rnd(Fd, K, dtype=torch.bfloat16, seed=62, scale=0.05).cuda()                 # W_down^T: [ffn, d]
     gate, up = rnd(M, Fd, dtype=torch.bfloat16, seed=63), rnd(M, Fd, dtype=torch.bfloat16, seed=64)
