@@ -164,10 +164,12 @@ int egomi_gemm(const egomi_gemm_desc* desc, egomi_stream_t stream);
 /* which kernel egomi_gemm would run for this descriptor: 2 = the 8-phase bf16 NT kernel (256x256 tiles, per-tile or persistent, or the
  * 352x256 form below), 1 = 128x128 / 256x128 bf16 NT kernel, 0 = generic */
 int egomi_gemm_kernel_id(const egomi_gemm_desc* desc);
-/* 352x256 form of the 8-phase kernel (gemm_nt_bf16_tall_kernel): one whole round where 256x256 tiles leave a ragged last one (M = 5536, N = 4096:
- * 256 tiles instead of 352).  mode 0 = never, 1 = by the library's round model (default), 2 = wherever it applies (M % 8 == 0, N % 8 == 0,
- * M >= 352, K >= 2048, plain or EGOMI_EPI_SLABS epilogue), -1 = back to EGOMI_GEMM_TALL / the default.  A product that takes this form has no
- * K-sliced tail rows (egomi_gemm_tail_plan: slices = 0).  Full tiles are bit-identical to the 256x256 form's (same K order per element).
+/* 352x256 form of the 8-phase kernel (gemm_nt_bf16_tall_kernel): whole rounds where 256x256 tiles leave a ragged last one (M = 5536, N = 4096:
+ * 16 x 16 = 256 tiles instead of 22 x 16 = 352).  mode 0 = never, 1 = by the library's round model (default) — the whole product in this form, or
+ * its first Na columns in this form and the rest on 256x256 tiles where neither fits alone (gate|up, the down_proj data gradient) —, 2 = the whole
+ * product wherever the form applies (M % 8 == 0, N % 8 == 0, M >= 352, K >= 2048; plain, EGOMI_EPI_SLABS, EGOMI_EPI_SWIGLU, EGOMI_EPI_SWIGLU_BWD),
+ * -1 = back to EGOMI_GEMM_TALL / the default.  A product that takes this form whole has no K-sliced tail rows (egomi_gemm_tail_plan: slices = 0).
+ * Whole tiles are bit-identical to the 256x256 form's (same K order per element), fused epilogues included.
  * Process-wide, not thread-safe: measurement and tests only.  No reference counterpart (torch.nn.Linear's GEMM is the vendor library's). */
 int egomi_gemm_set_tall(int mode);
 int egomi_gemm_slab_count(const egomi_gemm_desc* desc);   /* EGOMI_EPI_SLABS: slices egomi_gemm will leave for this descriptor, 0 = none */
