@@ -329,7 +329,8 @@ def main():
     # AdamW under the next step's forward pass (EgoAdamW.step(overlap=True)) where most parameters train: unfrozen 226.8 -> 224.1 ms.  With the frozen LLM
     # (1.4 ms of AdamW) it measured -0.35 ... +0.5 ms — the update's waves slow the latency-bound point branch it lands on (FPS 0.57 -> 1.18 ms) — so the
     # headline mode keeps the plain step.  EGOMI_OPT_OVERLAP=0 / 1 forces either (A/B runs)
-    OVERLAP_OPT = os.environ.get("EGOMI_OPT_OVERLAP", "1" if a.mode == "unfrozen" else "0") != "0"
+    OVERLAP_ENV = os.environ.get("EGOMI_OPT_OVERLAP")                               # default: overlapped where decoder layers train (also the `unfrozen` leg of config.extra)
+    EARLY_ENV = os.environ.get("EGOMI_OPT_EARLY", "1") != "0"                      # EgoAdamW.arm(): per-layer updates as soon as a layer's gradients are final
 
     def barrier():
         if world > 1:
@@ -337,11 +338,16 @@ def main():
 
     def measure(model, opt, sync, steps, warmup, gemm_event_steps, smi):
         """`warmup` untimed steps, then exactly `steps` steps between barrier + synchronize on both sides (the bench contract)."""
+        OVERLAP_OPT = (OVERLAP_ENV != "0") if OVERLAP_ENV is not None else model.engine.any_layer_trainable
+        EARLY_OPT = OVERLAP_OPT and EARLY_ENV
+
         def step(check=False):
             pts, col, cnt = ops.unproject_gather(rgb, depth, pp, fx, fx, synth.DEPTH_THRESHOLD, n_out=N)        # A1
             if check and int(cnt.min()) < N:
                 raise RuntimeError("synthetic clip has too few valid pixels")
             pc = ops.pc_norm(pts, col)                                                                            # A2
+            if EARLY_OPT and sync is None:
+                opt.arm(grad_scale=1.0)                                       # trainable decoder layers: AdamW under the backward pass of the layers below (one rank)
             loss = model.loss_and_backward(toks, masks, pc, Lp, dims.tok.pad, fps_start=fps_start)                # A3-A15
             if sync is not None:
                 sync.finish()

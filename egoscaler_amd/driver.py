@@ -270,6 +270,8 @@ def train(args, model, train_data, val_data=None, device="cuda", log=print, step
                 last = a == n_mb - 1
                 model.accumulate_grads = a > 0                                      # first micro-batch overwrites (optimizer.zero_grad(), train.py:159)
                 model.engine.grad_sync = sync if last else None                     # reduce once, after the last micro-batch
+                if last and sync is None:                                           # one rank: trainable decoder layers are updated under this backward pass
+                    opt.arm(grad_scale=1.0 / (n_mb * world), lr=linear_warmup_lr(float(args.lr_llm), global_step, total_steps))
                 loss = model.loss_and_backward(batch["tokens"], batch["attention_masks"], batch["pcrgbs"], batch["prompts"].shape[1],
                                                model.dims.tok.pad, fps_start=torch.zeros(len(idx), dtype=torch.int32, device=device))
                 run += loss / n_mb

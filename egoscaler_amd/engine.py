@@ -62,6 +62,7 @@ class Engine:
         self.reduced_grad = {}         # resident exchange (dp.GradSync(resident=True)): name -> bf16 view of the rank-summed gradient in the
         self.layer_offs = {}           # layer's wire buffer, read by EgoAdamW; layer_offs[l][name] = element offset inside the layer's flat block
         self._direct, self._direct_done = None, set()
+        self.layer_final_hook = None   # EgoAdamW.arm(): called with l when decoder layer l's gradients are final (one rank, last backward of the step)
         self.param_events = {}         # EgoAdamW.step(overlap=True): group ("pre" | "embed" | layer index | "post") -> event of its side-stream update
         self.use_fused_attention = True
         self.use_fused_swiglu = os.environ.get("EGOMI_NO_FUSED_SWIGLU", "0") != "1"   # SwiGLU in the gate|up GEMM epilogue where the 256x256
@@ -105,7 +106,10 @@ class Engine:
 
     def _notify_layer(self, l):
         """A decoder layer's gradients are final: its flat block goes out as one bucket (bucketed per layer,
-        reverse layer order, overlapped with the rest of backward)."""
+        reverse layer order, overlapped with the rest of backward).  Without an exchange (one rank) an armed optimizer may update the layer
+        right away (EgoAdamW.arm: the update runs on its side stream under the backward of the layers below)."""
+        if self.grad_sync is None and self.layer_final_hook is not None:
+            self.layer_final_hook(l)
         if self.grad_sync is None or l not in self.layer_flat:
             return
         if self._direct is not None:

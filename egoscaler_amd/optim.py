@@ -16,7 +16,45 @@ class EgoAdamW:
                 master = p.data if p.dtype == torch.float32 else p.data.float()
                 self.state[n] = {"p": p, "master": master, "m": torch.zeros_like(master), "v": torch.zeros_like(master)}
 
-    def _update(self, n, st, eng, lr, grad_scale):
+    def arm(self, grad_scale=1.0, lr=None):
+        """Call right before the LAST backward pass of an optimizer step (one rank, the step about to follow with step(overlap=True) and the same
+        grad_scale / lr): every decoder layer is then updated as soon as ITS gradients are final (Engine._notify_layer), on the side stream, under the
+        backward pass of the layers below it — the update is HBM-bound and gets the chip whenever the compute stream runs something that leaves
+        registers free (attention, norms, RoPE; the 8-phase GEMM does not), instead of queueing all 38 ms of it behind the backward pass.  step()
+        then handles what is left (projector / point backbone, embedding, final norm, lm_head).  Values are the same as the plain step's.
+        Returns False (and arms nothing) where that is not possible: an exchange is attached (gradients are not final until it has run), no CUDA
+        device, or resident W^T copies of trainable weights that a later product of this backward could still read."""
+        eng = self.model.engine
+        self._armed = None
+        eng.layer_final_hook = None
+        if eng.grad_sync is not None or eng.device.type != "cuda" or not eng.any_layer_trainable:
+            return False
+        if any(nm in eng.trainable for nm in getattr(eng, "wT", {})):      # (EGOMI_GEMM_TN=0 route; before the first forward pass the hook looks again)
+            return False
+        groups = {}
+        for n in self.state:
+            groups.setdefault(eng.param_group_of(n), []).append(n)
+        self._armed = {"lr": self.lr if lr is None else lr, "grad_scale": grad_scale, "done": set(), "groups": groups}
+        eng.layer_final_hook = self._early_layer
+        return True
+
+    def _early_layer(self, l):
+        a, eng = self._armed, self.model.engine
+        names = a["groups"].get(l)
+        if not names or any(nm in eng.trainable for nm in eng.wT):
+            return
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream()
+        self._side.wait_stream(torch.cuda.current_stream())       # the layer's gradients are final; every reader of its old weights has been queued
+        with torch.cuda.stream(self._side):
+            for n in names:
+                self._update(n, self.state[n], eng, a["lr"], a["grad_scale"], t=self.t + 1)
+            ev = torch.cuda.Event()
+            ev.record(self._side)
+            eng.param_events[l] = ev
+        a["done"].add(l)
+
+    def _update(self, n, st, eng, lr, grad_scale, t=None):
         g = eng.reduced_grad.get(n)                        # resident exchange (dp.GradSync(resident=True)): the rank-summed bf16 gradient, read
         if g is None:                                      # in place from the layer's wire buffer
             g = eng.main_grad.get(n)
@@ -24,7 +62,7 @@ class EgoAdamW:
             return
         p = st["p"]
         copy = None if p.dtype == torch.float32 else p.data
-        ops.adamw(st["master"], copy, g, st["m"], st["v"], lr, self.betas[0], self.betas[1], self.eps, self.wd, self.t, grad_scale)
+        ops.adamw(st["master"], copy, g, st["m"], st["v"], lr, self.betas[0], self.betas[1], self.eps, self.wd, self.t if t is None else t, grad_scale)
 
     def step(self, grad_scale=1.0, lr=None, overlap=False):
         """overlap=True (training loops that go straight on to the next forward pass: bench.py, driver.train): the updates run on a side stream in
@@ -36,10 +74,16 @@ class EgoAdamW:
         self.t += 1
         lr = self.lr if lr is None else lr
         eng = self.model.engine
+        armed, self._armed = getattr(self, "_armed", None), None
+        eng.layer_final_hook = None
+        early = armed["done"] if armed is not None else set()       # decoder layers arm() has already updated under the backward pass
+        if early and (armed["lr"] != lr or armed["grad_scale"] != grad_scale):
+            raise RuntimeError("EgoAdamW.step: lr / grad_scale differ from the ones given to arm()")
         if not (overlap and eng.device.type == "cuda" and not any(nm in eng.trainable for nm in eng.wT)):
             eng.wait_param_updates()
             for n, st in self.state.items():
-                self._update(n, st, eng, lr, grad_scale)
+                if eng.param_group_of(n) not in early:
+                    self._update(n, st, eng, lr, grad_scale)
             eng.after_weights_update()
             return
         groups = {}
@@ -54,7 +98,7 @@ class EgoAdamW:
         with torch.cuda.stream(self._side):
             for key in order:
                 names = groups.get(key)
-                if not names:
+                if not names or key in early:
                     continue
                 for n in names:
                     self._update(n, self.state[n], eng, lr, grad_scale)

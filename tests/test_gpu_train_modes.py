@@ -197,6 +197,51 @@ def test_overlapped_optimizer_step_equals_the_plain_one(unfreeze):
     assert oa["t"] == ob["t"] == 3
 
 
+def test_armed_optimizer_updates_layers_under_the_backward_pass_and_equals_the_plain_step():
+    """EgoAdamW.arm() (round 4): with every decoder layer trainable and one rank, layer l is updated on the side stream as soon as ITS
+    gradients are final — under the backward pass of the layers below — and step(overlap=True) finishes the rest.  Same losses, weights and
+    optimizer moments, bit for bit, as the plain step over three steps; the hook really ran for every layer; with lr / grad_scale that differ
+    from arm()'s, step() refuses; frozen decoder layers arm nothing."""
+    from egoscaler_amd.optim import EgoAdamW
+    dims = _dims()
+    toks, masks, Lp = synth.synth_batch(dims, 4, text_len=8, num_steps=4, max_traj_token=40)
+    pts = torch.stack([synth.synth_cloud(dims, i) for i in range(4)])
+    start = [0, 17, 3, 9]
+    res = {}
+    for early in (False, True):
+        m = _model(dims, True, torch.bfloat16)
+        m.train()
+        opt = EgoAdamW(m, lr=2e-3, weight_decay=0.01)
+        losses, seen = [], []
+        for i in range(3):
+            if early:
+                assert opt.arm(grad_scale=0.5, lr=1e-3 * (i + 1))
+                hook = m.engine.layer_final_hook
+                m.engine.layer_final_hook = lambda l, hook=hook: (seen.append(l), hook(l))[1]
+            losses.append(float(m.loss_and_backward(toks.cuda(), masks.cuda(), pts.cuda(), Lp, dims.tok.pad, fps_start=start)))
+            opt.step(grad_scale=0.5, lr=1e-3 * (i + 1), overlap=early)
+            assert m.engine.layer_final_hook is None
+        if early:
+            L = dims.lm.num_hidden_layers
+            assert seen == list(reversed(range(L))) * 3, seen
+        sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+        res[early] = (losses, sd, opt.state_dict_cpu())
+        if early:
+            opt.arm(grad_scale=0.5, lr=1e-3)
+            m.loss_and_backward(toks.cuda(), masks.cuda(), pts.cuda(), Lp, dims.tok.pad, fps_start=start)
+            with pytest.raises(RuntimeError):
+                opt.step(grad_scale=1.0, lr=1e-3, overlap=True)
+    (la, sa, oa), (lb, sb, ob) = res[False], res[True]
+    assert la == lb, (la, lb)
+    for k in sa:
+        assert torch.equal(sa[k], sb[k]), k
+    for n in oa["state"]:
+        for part in ("master", "m", "v"):
+            assert torch.equal(oa["state"][n][part], ob["state"][n][part]), (n, part)
+    mf = _model(dims, False, torch.bfloat16)
+    assert EgoAdamW(mf, lr=1e-3).arm() is False and mf.engine.layer_final_hook is None
+
+
 @pytest.mark.parametrize("unfreeze", [False, True])
 def test_zero_grad_after_an_overlapped_step_waits_for_the_update(unfreeze):
     """The reference loop's order (train.py:159-184: zero_grad at the top of the next iteration, after step) with step(overlap=True): the
