@@ -846,7 +846,13 @@ void gemm_nt_bf16_8phase_kernel(FastArgs g) {
 __device__ __forceinline__ void tl_dma(const char* gbase, uint32_t voff, uint32_t lds_base) {
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voff), "s"(gbase), "s"(lds_base) : "memory");
 }
-template <typename TC>
+typedef __attribute__((ext_vector_type(4))) __bf16 tl_bf16x4;
+typedef __attribute__((address_space(3))) tl_bf16x4 tl_lds_bf16x4;
+// TBK: B is k-major ([K][N], row stride ldb: a data gradient dX = dY . W against the weight as it lies in memory, gemm_tn.hip's TB operand): its halves are the
+// [64 k][128 columns] images of gemm_bf16_8phase_t_kernel (256-B rows, T10 image (b) swizzle, 4-row DMA pieces, fragments by two ds_read_b64_tr_b16), wave column wc
+// owns columns {128 X + 32 wc + 0..31 : X = 0, 1} of the tile; everything else — A side, phases, DMA counts per phase, vmcnt arithmetic — is the same kernel.
+// Needs N % 256 == 0 (no column clamp) and K % 64 == 0; plain bf16 store only.
+template <typename TC, bool TBK>
 __global__ __launch_bounds__(512, 2)
 void gemm_nt_bf16_tall_kernel(FastArgs g) {
     __shared__ __attribute__((aligned(16))) char smem[2 * TL_BUFB];
@@ -888,14 +894,27 @@ void gemm_nt_bf16_tall_kernel(FastArgs g) {
     for (int h = 0; h < 2; ++h)
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const int gi = gb + 4 * h + 16 * i;
-            int r = n0 + gi * 8; r = r < g.N - 8 ? r : g.N - 8;
-            sB[h][i] = __builtin_amdgcn_readfirstlane((uint32_t)(r * (int)g.ldb) * 2u);
-            lB[h][i] = __builtin_amdgcn_readfirstlane(lds0 + TL_AB + gi * 1024);
+            if (TBK) {                                                  // piece wave*2+i = k-rows 4*(wave*2+i) .. +3 of half h's image
+                sB[h][i] = __builtin_amdgcn_readfirstlane((uint32_t)(n0 + 128 * h) * 2u);
+                lB[h][i] = __builtin_amdgcn_readfirstlane(lds0 + TL_AB + h * 16384 + (wave * 2 + i) * 1024);
+            } else {
+                const int gi = gb + 4 * h + 16 * i;
+                int r = n0 + gi * 8; r = r < g.N - 8 ? r : g.N - 8;
+                sB[h][i] = __builtin_amdgcn_readfirstlane((uint32_t)(r * (int)g.ldb) * 2u);
+                lB[h][i] = __builtin_amdgcn_readfirstlane(lds0 + TL_AB + gi * 1024);
+            }
         }
     const uint32_t dchunk = (lane & 7) ^ ((((wave & 1) << 2) + (lane >> 4)) & 7);
     const uint32_t vA = (uint32_t)((lane >> 3) * (int)g.lda + (int)dchunk * 8) * 2u;
-    const uint32_t vB = (uint32_t)((lane >> 3) * (int)g.ldb + (int)dchunk * 8) * 2u;
+    uint32_t vB[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        if (TBK) {
+            const int r = (wave * 2 + i) * 4 + (lane >> 4);             // k-row of the image
+            const int ch = (lane & 15) ^ (((r & 3) << 2) | ((r >> 2) & 3));
+            vB[i] = (uint32_t)(r * (int)g.ldb + 8 * ch) * 2u;
+        } else vB[i] = (uint32_t)((lane >> 3) * (int)g.ldb + (int)dchunk * 8) * 2u;
+    }
 
     f32x4 acc[4][TL_NB];
 #pragma unroll
@@ -905,15 +924,27 @@ void gemm_nt_bf16_tall_kernel(FastArgs g) {
 
     // fragment read offsets (bytes) inside a buffer
     const int sw = ((lane & 15) >> 1) & 7, c0 = lane >> 4;
-    int aRd[2], bRd[2];
+    int aRd[2], bRd[TBK ? 4 : 2];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
         aRd[ks] = (wr * (16 * TL_NB) + (lane & 15)) * 128 + (((c0 + 4 * ks) ^ sw) << 4);
-        bRd[ks] = TL_AB + (wc * 64 + (lane & 15)) * 128 + (((c0 + 4 * ks) ^ sw) << 4);
+        if (!TBK) bRd[ks] = TL_AB + (wc * 64 + (lane & 15)) * 128 + (((c0 + 4 * ks) ^ sw) << 4);
+    }
+    if (TBK) {                                                          // bRd[jj * 2 + e]: the two transposed 8-byte reads of column block jj (gemm_tn.hip TnSide<true>)
+        const int gq = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int row = 8 * gq + q + 4 * e;                     // + 32 ks: an immediate
+                const int ch = (wc * 32 + 16 * jj) / 8 + (pp >> 1);
+                bRd[jj * 2 + e] = TL_AB + 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3))) + 8 * (pp & 1);
+            }
     }
     const int nt = g.K / FT_BK, t_last = nt - 1;
     const char* Ab = reinterpret_cast<const char*>(g.A);
     const char* Bb = reinterpret_cast<const char*>(g.B);
+    const long long strideB = TBK ? 128ll * g.ldb : 128ll;             // bytes per K-tile of B
 
     bf16x8 fa[2][4], fb0[2][2], fb1[2][2];
     // (bo = byte offset of the tile's buffer, bn = of the other one: scalars; the per-lane read offsets aRd / bRd are advanced from buffer to buffer,
@@ -921,11 +952,16 @@ void gemm_nt_bf16_tall_kernel(FastArgs g) {
 #define TL_RD(off) (*reinterpret_cast<const bf16x8*>(smem + (off)))
 #define TL_LDA(c, n) _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int ii = 0; ii < (n); ++ii) \
         fa[ks][ii] = TL_RD(aRd[ks] + ((c) * 64 + ii * 16) * 128);
-#define TL_LDB(dst, X) _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int jj = 0; jj < 2; ++jj) \
-        dst[ks][jj] = TL_RD(bRd[ks] + ((X) * 32 + jj * 16) * 128);
+#define TL_LDB(dst, X) _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int jj = 0; jj < 2; ++jj) { \
+        if (TBK) { \
+            const tl_bf16x4 lo_ = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((tl_lds_bf16x4*)(smem + bRd[(TBK ? jj * 2 : 0)] + (X) * 16384 + ks * 8192)); \
+            const tl_bf16x4 hi_ = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((tl_lds_bf16x4*)(smem + bRd[(TBK ? jj * 2 + 1 : 0)] + (X) * 16384 + ks * 8192)); \
+            bf16x8 r_; r_[0] = lo_[0]; r_[1] = lo_[1]; r_[2] = lo_[2]; r_[3] = lo_[3]; r_[4] = hi_[0]; r_[5] = hi_[1]; r_[6] = hi_[2]; r_[7] = hi_[3]; \
+            dst[ks][jj] = r_; \
+        } else dst[ks][jj] = TL_RD(bRd[ks] + ((X) * 32 + jj * 16) * 128); }
 #define TL_PFA(bo_, c, base) { tl_dma((base) + sA[c][0], vA, lA[c][0] + (bo_)); \
         if ((c) < 2 || wave < 4) tl_dma((base) + sA[c][1], vA, lA[c][1] + (bo_)); }
-#define TL_PFB(bo_, h, base) { tl_dma((base) + sB[h][0], vB, lB[h][0] + (bo_)); tl_dma((base) + sB[h][1], vB, lB[h][1] + (bo_)); }
+#define TL_PFB(bo_, h, base) { tl_dma((base) + sB[h][0], vB[0], lB[h][0] + (bo_)); tl_dma((base) + sB[h][1], vB[1], lB[h][1] + (bo_)); }
 #define TL_MMA(c, n, fbv, X) __builtin_amdgcn_s_setprio(1); \
         _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int jj = 0; jj < 2; ++jj) _Pragma("unroll") for (int ii = 0; ii < (n); ++ii) \
             acc[(X) * 2 + jj][(c) * 4 + ii] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fbv[ks][jj], fa[ks][ii], acc[(X) * 2 + jj][(c) * 4 + ii], 0, 0, 0); \
@@ -947,7 +983,7 @@ void gemm_nt_bf16_tall_kernel(FastArgs g) {
     {
         const int t1 = 1 < t_last ? 1 : t_last;
         const char* pA1 = Ab + (long long)t1 * 128;
-        const char* pB1 = Bb + (long long)t1 * 128;
+        const char* pB1 = Bb + (long long)t1 * strideB;
         TL_PFB(0, 0, Bb) TL_PFA(0, 0, Ab) TL_PFB(0, 1, Bb) TL_PFA(0, 1, Ab) TL_PFA(0, 2, Ab)
         TL_PFB(TL_BUFB, 0, pB1) TL_PFA(TL_BUFB, 0, pA1) TL_PFB(TL_BUFB, 1, pB1) TL_PFA(TL_BUFB, 1, pA1)
         asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
@@ -962,7 +998,7 @@ void gemm_nt_bf16_tall_kernel(FastArgs g) {
         const int t1 = (TL_ABL & 16) ? 0 : (t + 1 < t_last ? t + 1 : t_last), t2 = (TL_ABL & 16) ? 0 : (t + 2 < t_last ? t + 2 : t_last);     // (16: every DMA re-reads K-tile 0 — L2-hot)
         const char* pA1 = Ab + (long long)t1 * 128;
         const char* pA2 = Ab + (long long)t2 * 128;
-        const char* pB2 = Bb + (long long)t2 * 128;
+        const char* pB2 = Bb + (long long)t2 * strideB;
         /* ph1 */ TL_LDA_(0, 4) TL_BAR TL_MMA_(0, 4, fb0, 0) TL_BAR2
         /* ph2 */ TL_LDB_(fb1, 1) TL_PFB_(bo, 0, pB2) TL_BAR TL_MMA_(0, 4, fb1, 1) TL_BAR2
         /* ph3 */ TL_LDA_(1, 4) TL_PFA_(bo, 0, pA2) TL_BAR TL_MMA_(1, 4, fb1, 1) TL_BAR2
@@ -973,7 +1009,9 @@ void gemm_nt_bf16_tall_kernel(FastArgs g) {
         {
             const int dl = (t & 1) ? -TL_BUFB : TL_BUFB;
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) { aRd[ks] += dl; bRd[ks] += dl; }
+            for (int ks = 0; ks < 2; ++ks) aRd[ks] += dl;
+#pragma unroll
+            for (int q = 0; q < (TBK ? 4 : 2); ++q) bRd[q] += dl;
         }
         TL_LDB_(fb0, 0) TL_PFA_(bn, 2, pA1)
         TL_BAR TL_MMA_(2, 3, fb1, 1) TL_BAR2
@@ -989,6 +1027,7 @@ void gemm_nt_bf16_tall_kernel(FastArgs g) {
 #undef TL_LDA
 #undef TL_RD
     const int mb = m0 + wr * (16 * TL_NB), nb = n0 + wc * 64;
+    if (TBK && (sizeof(TC) != 2 || g.bias || g.residual || g.accumulate || g.act != 0 || g.alpha != 1.0f || g.epi != 0 || (g.ldc & 7) || ((uintptr_t)g.C & 15))) return;   // (the launcher admits the plain bf16 store only)
     if (sizeof(TC) == 2 && !g.bias && !g.accumulate && g.act == 0 && g.alpha == 1.0f && nb + 64 <= g.N && (g.ldc & 7) == 0 && ((uintptr_t)g.C & 15) == 0 &&
         (!g.residual || ((g.ldr & 7) == 0 && ((uintptr_t)g.residual & 15) == 0))) {      // wave-uniform
         bf16_t* C = reinterpret_cast<bf16_t*>(g.C);
@@ -1114,7 +1153,9 @@ void gemm_nt_bf16_tall_kernel(FastArgs g) {
                 if (it * 8 >= nblk * 16) continue;
                 const u32x4 v = *reinterpret_cast<const u32x4*>(wb + r * 144 + ch * 16);
                 const int m = mb + pass * 64 + r;
-                if (m < g.M) *reinterpret_cast<u32x4*>(C + (long long)m * g.ldc + nb + ch * 8) = v;
+                // (k-major B: the wave's 64 columns are two groups of 32, 128 columns apart — strip columns 0-31 / 32-63)
+                const int ncol = TBK ? n0 + 128 * (ch >> 2) + 32 * wc + (ch & 3) * 8 : nb + ch * 8;
+                if (m < g.M) *reinterpret_cast<u32x4*>(C + (long long)m * g.ldc + ncol) = v;
             }
             if (g.epi == 1) {
                 // SwiGLU in the epilogue (the 256x256 form's, same rounding sequence): the wave's 64 columns are one interleaved-32 group, gate in
@@ -1151,7 +1192,7 @@ void gemm_nt_bf16_tall_kernel(FastArgs g) {
         }
         return;
     }
-    gemm_epilogue<TC, TL_NB>(g, acc, mb, nb, lane);
+    if (!TBK) gemm_epilogue<TC, TL_NB>(g, acc, mb, nb, lane);
 }
 
 
@@ -1828,9 +1869,32 @@ static int launch_tall(const egomi_gemm_desc* d, FastArgs& g, hipStream_t s, hip
     g.full_tm = gdepth;
     const int nwg = g.tiles_m * g.tiles_n;
     if (t0) (void)hipEventRecord(t0, s);
-    if (d->c_dtype == EGOMI_BF16) EGOMI_LAUNCH(gemm_nt_bf16_tall_kernel<bf16_t>, dim3(nwg), dim3(512), 0, s, g);
-    else EGOMI_LAUNCH(gemm_nt_bf16_tall_kernel<float>, dim3(nwg), dim3(512), 0, s, g);
+    if (d->c_dtype == EGOMI_BF16) EGOMI_LAUNCH((gemm_nt_bf16_tall_kernel<bf16_t, false>), dim3(nwg), dim3(512), 0, s, g);
+    else EGOMI_LAUNCH((gemm_nt_bf16_tall_kernel<float, false>), dim3(nwg), dim3(512), 0, s, g);
     if (t1) (void)hipEventRecord(t1, s);
+    return egomi_launch_status();
+}
+
+// data gradient against a k-major weight (a_layout 0, b_layout 1; called by gemm_tn.hip before its own 256x256 kernel): the 352x256 form where the round
+// model prefers it.  -> 0 launched, 1 not applicable, < 0 error.  `query`: decide only.
+int egomi_tall_kmajor_try(const egomi_gemm_desc* d, hipStream_t s, bool query) {
+    static int on = -1;                                                  // EGOMI_GEMM_TALL_KMAJOR=0: gemm_tn.hip's 256x256 kernel for every k-major product (A/B runs)
+    if (on < 0) { const char* e = getenv("EGOMI_GEMM_TALL_KMAJOR"); on = e ? atoi(e) : 1; }
+    if (!on) return 1;
+    if (d->a_layout != 0 || d->b_layout != 1 || d->ab_dtype != EGOMI_BF16 || d->c_dtype != EGOMI_BF16 || d->batch > 1) return 1;
+    if (d->bias || d->residual || d->accumulate || d->act != 0 || d->alpha != 1.0f || d->epilogue != EGOMI_EPI_NONE) return 1;
+    if ((d->N & 255) || (d->K % FT_BK) || (d->lda & 7) || (d->ldb & 7) || (d->ldc & 7) || (((uintptr_t)d->A | (uintptr_t)d->B | (uintptr_t)d->C) & 15)) return 1;
+    if (d->lda < d->K || d->ldb < d->N) return 1;
+    egomi_gemm_desc dn = *d;                                             // the shape rules and the round model of the K-contiguous form
+    dn.b_layout = 0; dn.ldb = 8;                                         // (ldb only enters tall_form's 31-bit span check, which the k-major B does not need)
+    if (!tall_form(&dn)) return 1;
+    if (query) return 0;
+    FastArgs g = {};
+    g.A = (const bf16_t*)d->A; g.B = (const bf16_t*)d->B; g.C = d->C;
+    g.M = d->M; g.N = d->N; g.K = d->K; g.lda = d->lda; g.ldb = d->ldb; g.ldc = d->ldc; g.alpha = 1.0f;
+    g.tiles_m = (d->M + TL_BM - 1) / TL_BM; g.tiles_n = d->N / 256;
+    g.splitk = 1; g.full_tm = 8;
+    EGOMI_LAUNCH((gemm_nt_bf16_tall_kernel<bf16_t, true>), dim3(g.tiles_m * g.tiles_n), dim3(512), 0, s, g);
     return egomi_launch_status();
 }
 

@@ -323,6 +323,7 @@ void gemm_bf16_8phase_t_kernel(TnArgs g) {
 }
 
 // gemm_fast.hip
+int egomi_tall_kmajor_try(const egomi_gemm_desc* d, hipStream_t s, bool query);    // data gradients: the 352x256 form where whole rounds pay (0 = taken)
 void egomi_plan_tail_rows(int M, int N, int K, long long ws_bytes, int* rows, int* slices);
 int egomi_splitk_reduce_rows(void* C, int c_dtype, long long ldc, int rows, int N, const float* ws, int slices, int accumulate, hipStream_t s);
 
@@ -376,6 +377,7 @@ static void tn_tail(const egomi_gemm_desc* d, int* rows, int* slices, float** sl
 extern "C" int egomi_gemm_tn_tail_plan(const egomi_gemm_desc* d, int* row0, int* slices) {
     if (!d || !row0 || !slices) return EGOMI_E_BADARG;
     if (!tn_applicable(d)) return EGOMI_E_UNSUPPORTED;
+    if (egomi_tall_kmajor_try(d, nullptr, true) == 0) { *row0 = d->M; *slices = 0; return EGOMI_OK; }     // one whole round of 352x256 tiles: no K-sliced rows
     int r, sl; float* w;
     tn_tail(d, &r, &sl, &w);
     *row0 = r ? ((d->M + 255) / 256 - r) * 256 : d->M;
@@ -388,6 +390,7 @@ extern "C" int egomi_gemm_tn_kernel_id(const egomi_gemm_desc* d) { return (d && 
 // returns 0 on success, < 0 on error, 1 when this kernel does not apply
 int egomi_gemm_tn_try(const egomi_gemm_desc* d, hipStream_t s) {
     if (!tn_applicable(d)) return 1;
+    { const int rc = egomi_tall_kmajor_try(d, s, false); if (rc <= 0) return rc; }
     TnArgs g;
     g.A = (const bf16_t*)d->A; g.B = (const bf16_t*)d->B; g.C = d->C;
     g.M = d->M; g.N = d->N; g.K = d->K; g.lda = d->lda; g.ldb = d->ldb; g.ldc = d->ldc; g.accumulate = d->accumulate;

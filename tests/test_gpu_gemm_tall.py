@@ -111,3 +111,47 @@ def test_library_choice_at_the_step_shapes(ops, tall):
         assert t1 is None, (N, t1)
         ref = a.float() @ w.float().t()
         assert float((c.float() - ref).abs().max()) <= 2e-2 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("M,N,K", [(4096, 4096, 4096), (4096, 2048, 12288), (2048, 4096, 2112)])
+def test_tall_form_with_a_k_major_weight_is_bit_identical_to_the_k_major_256_form(ops, tall, M, N, K):
+    """Data gradient dX = dY . W against the weight as it lies in memory (b_layout = 1: gemm_tn.hip's product, kernel id 3): the 352x256 form with the
+    k-major B side (gemm_nt_bf16_tall_kernel<bf16, true>) against gemm_bf16_8phase_t_kernel on shapes whose 256x256 tiles are whole rounds (no K-sliced
+    rows in either): the same bits, and close to fp32."""
+    dy, w = rnd(M, K, seed=11).cuda(), rnd(K, N, seed=12, scale=0.05).cuda()
+    out = []
+    for mode in (0, 2):
+        tall(mode)
+        c = torch.full((M, N), 3.0, dtype=torch.bfloat16, device="cuda")
+        assert ops.mm_kernel_id(dy, w, c, b_layout=1) == 3
+        ops.mm(dy, w, out=c, b_layout=1)
+        torch.cuda.synchronize()
+        out.append(c)
+    ref = dy.float() @ w.float()
+    assert float((out[1].float() - ref).abs().max()) <= 2e-2 * float(ref.abs().max())
+    assert torch.equal(out[0], out[1])
+
+
+def test_k_major_data_gradient_at_the_step_shape_takes_the_tall_form(ops, tall):
+    """M = 5536, N = 4096 (the q|k|v, o and gate|up data gradients of a trainable layer): default mode reports no K-sliced rows (egomi_gemm_tn_tail_plan),
+    mode 0 does; the result is close to fp32 either way and the operands may end an allocation (test_gpu_bounds.py covers the placement)."""
+    import ctypes
+    from egoscaler_amd import _lib
+    M, N, K = 5536, 4096, 4096
+    dy, w = rnd(M, K, seed=21).cuda(), rnd(K, N, seed=22, scale=0.05).cuda()
+    ref = dy.float() @ w.float()
+    ws = torch.zeros(64 << 20, dtype=torch.uint8, device="cuda")
+    for mode, sliced in ((0, True), (1, False)):
+        tall(mode)
+        c = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+        d = ops.GemmDesc()
+        d.A, d.B, d.C = dy.data_ptr(), w.data_ptr(), c.data_ptr()
+        d.M, d.N, d.K, d.lda, d.ldb, d.ldc = M, N, K, K, N, N
+        d.a_layout, d.b_layout, d.ab_dtype, d.c_dtype, d.batch, d.batch_inner, d.alpha = 0, 1, ops.dt(dy.dtype), ops.dt(c.dtype), 1, 1, 1.0
+        d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
+        row0, slices = ctypes.c_int(0), ctypes.c_int(0)
+        assert _lib.lib().egomi_gemm_tn_tail_plan(ctypes.byref(d), ctypes.byref(row0), ctypes.byref(slices)) == 0
+        assert (slices.value >= 2) == sliced, (mode, row0.value, slices.value)
+        ops.mm(dy, w, out=c, b_layout=1, workspace=ws)
+        torch.cuda.synchronize()
+        assert float((c.float() - ref).abs().max()) <= 2e-2 * float(ref.abs().max())
