@@ -414,7 +414,8 @@ def main():
             except Exception:
                 traffic = None
         roof = {"bound": "mfma", "kernel": "the 8-phase bf16 GEMM = gemm_nt_bf16_8phase_kernel (256x256 tiles) + gemm_nt_bf16_tall_kernel (its 352x256 form; egomi_gemm_kernel_id 2: "
-                                           "in rocprofv3's kernel stats the two rows together, weighted by their calls) (every launch of %d of the %d timed steps; HIP events recorded by the library on the launch "
+                                           "in rocprofv3's kernel stats the two rows together; a launch here = one egomi_gemm product, which is two kernels back to back where the library splits a product's columns between the two forms) "
+                                           "(every product of %d of the %d timed steps; HIP events recorded by the library on the launch "
                                            "stream directly around the kernel, inside the timed region: egomi_gemm_time_next.  avg_call_ms is the whole egomi_gemm call, "
                                            "i.e. plus splitk_reduce_kernel where the tail rows are K-sliced)" % (len(ev_steps), a.steps),
                 "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS,
