@@ -4,7 +4,9 @@ timing per shape.  The form is chosen per process (EGOMI_GEMM_TALL=0|1|2 is read
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
-from egoscaler_amd import ops
+from egoscaler_amd import ops, _lib
+if os.environ.get("EGOMI_LIB"):                      # a variant build of the library (e.g. -DTL_SCHED=3)
+    _lib.LIB_PATH = os.environ["EGOMI_LIB"]
 
 mode = os.environ.get("EGOMI_GEMM_TALL", "1")
 if "check" in sys.argv:
