@@ -13,8 +13,9 @@ rng = random.Random(seed)
 torch.manual_seed(seed)
 bad = 0
 for it in range(n_shapes):
-    M = rng.choice([rng.randint(1, 300), rng.randint(300, 3000), rng.randint(3000, 6500), 5536, 4096])
-    N = rng.choice([rng.randint(8, 600), rng.randint(600, 5000), rng.randint(5000, 13000), 4096, 12288]) // 8 * 8
+    # (round 4: multiples of 8 around the 352x256 form's selection rule and the column split between the two tile forms — N = 11008 / 22016 at M ~ 5536)
+    M = rng.choice([rng.randint(1, 300), rng.randint(300, 3000), rng.randint(3000, 6500), 5536, 4096, rng.randint(44, 800) * 8, 5544, 2816])
+    N = rng.choice([rng.randint(8, 600), rng.randint(600, 5000), rng.randint(5000, 13000), 4096, 12288, 11008, 22016, rng.randint(4, 60) * 256]) // 8 * 8
     K = rng.choice([64, 128, 192, 2048, 2112, 4096, rng.randint(1, 100) * 64, rng.randint(32, 172) * 64])
     a = torch.randn(M, K, device="cuda").bfloat16()
     w = (torch.randn(N, K, device="cuda") * 0.05).bfloat16()
