@@ -1852,7 +1852,7 @@ static bool tall_form(const egomi_gemm_desc* d) {
     if ((long long)d->M * d->lda >= (1ll << 31) || (long long)d->N * d->ldb >= (1ll << 31)) return false;
     if (d->c_dtype != EGOMI_BF16 && d->c_dtype != EGOMI_F32) return false;
     if (mode == 2) return true;
-    const int ncu = 256;
+    const int ncu = p8_cus();                                            // CUs of this device (256 on MI355X in SPX mode)
     const long long tn = (d->N + 255) / 256;
     const long long t256 = (long long)((d->M + 255) / 256) * tn, t352 = (long long)((d->M + TL_BM - 1) / TL_BM) * tn;
     const int rem = (int)(t256 % ncu);
@@ -1996,7 +1996,7 @@ static int launch_8phase(const egomi_gemm_desc* d, FastArgs& g, hipStream_t s, i
 // 22 x 11 (0.95 rounds).  Same round model as tall_form(); both parts carry the product's epilogue (plain, SwiGLU, SwiGLU backward); the second
 // part plans its own K-sliced tail.  Na is a multiple of 256 columns, so interleaved-32 gate|up groups and 64-column wave strips stay whole.
 static double c256_model(long long tiles, bool ws) {
-    const int ncu = 256;
+    const int ncu = p8_cus();                                            // CUs of this device (256 on MI355X in SPX mode)
     const int rem = (int)(tiles % ncu);
     return (double)(tiles / ncu) + (rem ? (rem * 2 <= ncu && ws ? 0.28 + 0.85 * rem / ncu : 1.0) : 0.0);
 }
@@ -2009,7 +2009,7 @@ static int split_cols(const egomi_gemm_desc* d) {
     if ((d->M & 7) || (d->N & 255) || d->M < TL_BM || d->K < 2048 || d->split_k > 0 || d->bias) return 0;
     if ((long long)d->M * d->lda >= (1ll << 31) || (long long)d->N * d->ldb >= (1ll << 31)) return 0;
     if (d->c_dtype != EGOMI_BF16 && d->c_dtype != EGOMI_F32) return 0;
-    const int ncu = 256;
+    const int ncu = p8_cus();                                            // CUs of this device (256 on MI355X in SPX mode)
     const long long tn = d->N / 256, tm256 = (d->M + 255) / 256, tm352 = (d->M + TL_BM - 1) / TL_BM;
     const double c0 = c256_model(tm256 * tn, d->workspace != nullptr);
     double best = 0.97 * c0;

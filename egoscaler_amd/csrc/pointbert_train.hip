@@ -13,30 +13,38 @@
 // dw / db / the batch statistics / dgamma / dbeta / dW with atomicAdd, whose order — and with it the last bits of the train-mode
 // BatchNorm OUTPUT — changed from run to run).
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void ordered_partial_sum_kernel(const float* part, int P, long long W, float* out, int accumulate) {
-    const long long w = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (w >= W) return;
+// One 1024-thread block owns 32 columns: row lane rl (0..31) adds the partial rows p = rl, rl + 32, ... in increasing order, the 32 lane sums meet in LDS
+// and are added in lane order — a fixed association whatever the launch (the first form walked all P rows in one thread per column: 112 us for P = 512).
+// out[w] (+)= sum over p of part[p * stride + off + w], w < W.
+__global__ __launch_bounds__(1024) void ordered_partial_sum_strided_kernel(const float* part, int P, long long stride, long long off, long long W, float* out,
+                                                                           int accumulate) {
+    __shared__ float sm[32][33];
+    const int c = threadIdx.x & 31, rl = threadIdx.x >> 5;
+    const long long w = (long long)blockIdx.x * 32 + c;
     float s = 0.f;
-    for (int p = 0; p < P; ++p) s += part[(long long)p * W + w];
-    out[w] = accumulate ? out[w] + s : s;
+    if (w < W)
+        for (int p = rl; p < P; p += 32) s += part[(long long)p * stride + off + w];
+    sm[rl][c] = s;
+    __syncthreads();
+    if (rl == 0 && w < W) {
+        float t = 0.f;
+#pragma unroll
+        for (int r = 0; r < 32; ++r) t += sm[r][c];
+        out[w] = accumulate ? out[w] + t : t;
+    }
 }
-// out[w] += sum over p of part[p * stride + off + w], w < W (a column block of the partial rows)
-__global__ __launch_bounds__(256) void ordered_partial_sum_strided_kernel(const float* part, int P, long long stride, long long off, long long W, float* out) {
-    const long long w = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (w >= W) return;
-    float s = 0.f;
-    for (int p = 0; p < P; ++p) s += part[(long long)p * stride + off + w];
-    out[w] += s;
+static int ordered_partial_sum_cols(const float* part, int P, long long stride, long long off, long long W, float* out, int accumulate, hipStream_t s) {
+    EGOMI_LAUNCH(ordered_partial_sum_strided_kernel, dim3((unsigned)((W + 31) / 32)), dim3(1024), 0, s, part, P, stride, off, W, out, accumulate);
+    return egomi_launch_status();
 }
 static int ordered_partial_sum(const float* part, int P, long long W, float* out, int accumulate, hipStream_t s) {
-    EGOMI_LAUNCH(ordered_partial_sum_kernel, dim3((unsigned)((W + 255) / 256)), dim3(256), 0, s, part, P, W, out, accumulate);
-    return egomi_launch_status();
+    return ordered_partial_sum_cols(part, P, W, 0, W, out, accumulate, s);
 }
 
 // ------------------------------------------------------------------------------------------------
 // LayerNorm backward: dx = rstd*(g - mean(g) - xh*mean(g*xh)) (+ dx_add), g = w*dy;
 // dw += sum dy*xh, db += sum dy.  One wave per row; every wave keeps its own [2][cols] partial row in LDS (column c of wave v has ONE
-// writer: lane c % 64), the block adds its four rows in wave order into partials[block], ordered_partial_sum_kernel adds the blocks.
+// writer: lane c % 64), the block adds its four rows in wave order into partials[block], ordered_partial_sum_strided_kernel adds the blocks.
 // ------------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* dy, const T* x, const T* w, T* dx, const T* dx_add, float* part,
@@ -88,8 +96,8 @@ extern "C" int egomi_layernorm_bwd(const void* dy, const void* x, const void* w,
                                              (const T*)dy, (const T*)x, (const T*)w, (T*)dx, (const T*)dx_add, red ? partials : nullptr, rows, cols, eps));
     if (dw && db && db == dw + cols) return ordered_partial_sum(partials, grid, 2ll * cols, dw, 1, s);       // back to back: one pass
     // dw / db anywhere: a partial row is [dw cols | db cols], so each half is a strided view of it
-    if (dw) { EGOMI_LAUNCH(ordered_partial_sum_strided_kernel, dim3((cols + 255) / 256), dim3(256), 0, s, (const float*)partials, grid, 2ll * cols, 0ll, (long long)cols, dw); }
-    if (db) { EGOMI_LAUNCH(ordered_partial_sum_strided_kernel, dim3((cols + 255) / 256), dim3(256), 0, s, (const float*)partials, grid, 2ll * cols, (long long)cols, (long long)cols, db); }
+    if (dw) { const int rc = ordered_partial_sum_cols(partials, grid, 2ll * cols, 0, cols, dw, 1, s); if (rc != EGOMI_OK) return rc; }
+    if (db) { const int rc = ordered_partial_sum_cols(partials, grid, 2ll * cols, cols, cols, db, 1, s); if (rc != EGOMI_OK) return rc; }
     return egomi_launch_status();
 }
 
@@ -206,8 +214,8 @@ extern "C" int egomi_bn_train_bwd(const void* dy, const void* x, const void* y, 
     EGOMI_DISPATCH_DTYPE(dtype, {
         EGOMI_LAUNCH(bn_bwd_reduce_kernel<T>, g1, dim3(256), 0, s, (const T*)dy, (const T*)x, (const T*)y, (long long)R, C, stats + 2 * C, stats + 3 * C, relu,
                      partials, rpb);
-        EGOMI_LAUNCH(ordered_partial_sum_strided_kernel, dim3((C + 255) / 256), dim3(256), 0, s, (const float*)partials, nby, 2ll * C, 0ll, (long long)C, dgamma);
-        EGOMI_LAUNCH(ordered_partial_sum_strided_kernel, dim3((C + 255) / 256), dim3(256), 0, s, (const float*)partials, nby, 2ll * C, (long long)C, (long long)C, dbeta);
+        { const int rc = ordered_partial_sum_cols(partials, nby, 2ll * C, 0, C, dgamma, 1, s); if (rc != EGOMI_OK) return rc; }
+        { const int rc = ordered_partial_sum_cols(partials, nby, 2ll * C, C, C, dbeta, 1, s); if (rc != EGOMI_OK) return rc; }
         EGOMI_LAUNCH(bn_bwd_apply_kernel<T>, dim3(g2), dim3(256), 0, s, (const T*)dy, (const T*)x, (const T*)y, (long long)R, C, stats + 2 * C, stats + 3 * C,
                      (const T*)gamma, relu, dgamma, dbeta, (T*)dx);
     });
