@@ -1875,6 +1875,8 @@ static int launch_tall(const egomi_gemm_desc* d, FastArgs& g, hipStream_t s, hip
     return egomi_launch_status();
 }
 
+int egomi_gemm_tn_rest(const egomi_gemm_desc* d, hipStream_t s);        // gemm_tn.hip: its 256x256 kernel, without trying this form again
+static int split_cols(const egomi_gemm_desc* d);
 // data gradient against a k-major weight (a_layout 0, b_layout 1; called by gemm_tn.hip before its own 256x256 kernel): the 352x256 form where the round
 // model prefers it.  -> 0 launched, 1 not applicable, < 0 error.  `query`: decide only.
 int egomi_tall_kmajor_try(const egomi_gemm_desc* d, hipStream_t s, bool query) {
@@ -1887,15 +1889,24 @@ int egomi_tall_kmajor_try(const egomi_gemm_desc* d, hipStream_t s, bool query) {
     if (d->lda < d->K || d->ldb < d->N) return 1;
     egomi_gemm_desc dn = *d;                                             // the shape rules and the round model of the K-contiguous form
     dn.b_layout = 0; dn.ldb = 8;                                         // (ldb only enters tall_form's 31-bit span check, which the k-major B does not need)
-    if (!tall_form(&dn)) return 1;
-    if (query) return 0;
+    int Na = d->N;                                                       // columns in this form: all of them, or (column split, as split_cols) the first Na
+    if (!tall_form(&dn)) {
+        Na = split_cols(&dn);
+        if (!Na) return 1;
+    }
+    if (query) return Na == d->N ? 0 : 1;                                // (a split product's second part plans its own K-sliced rows: no plan to report here)
     FastArgs g = {};
     g.A = (const bf16_t*)d->A; g.B = (const bf16_t*)d->B; g.C = d->C;
-    g.M = d->M; g.N = d->N; g.K = d->K; g.lda = d->lda; g.ldb = d->ldb; g.ldc = d->ldc; g.alpha = 1.0f;
-    g.tiles_m = (d->M + TL_BM - 1) / TL_BM; g.tiles_n = d->N / 256;
+    g.M = d->M; g.N = Na; g.K = d->K; g.lda = d->lda; g.ldb = d->ldb; g.ldc = d->ldc; g.alpha = 1.0f;
+    g.tiles_m = (d->M + TL_BM - 1) / TL_BM; g.tiles_n = Na / 256;
     g.splitk = 1; g.full_tm = 8;
     EGOMI_LAUNCH((gemm_nt_bf16_tall_kernel<bf16_t, true>), dim3(g.tiles_m * g.tiles_n), dim3(512), 0, s, g);
-    return egomi_launch_status();
+    if (Na == d->N) return egomi_launch_status();
+    egomi_gemm_desc d2 = *d;                                             // the rest on gemm_tn.hip's 256x256 tiles (its own tail plan)
+    d2.N = d->N - Na;
+    d2.B = (const bf16_t*)d->B + Na;
+    d2.C = (bf16_t*)d->C + Na;
+    return egomi_gemm_tn_rest(&d2, s);
 }
 
 // the tail plan launch_8phase will run for this descriptor (d->workspace already points at the slab area)

@@ -323,6 +323,7 @@ void gemm_bf16_8phase_t_kernel(TnArgs g) {
 }
 
 // gemm_fast.hip
+int egomi_gemm_tn_rest(const egomi_gemm_desc* d, hipStream_t s);
 int egomi_tall_kmajor_try(const egomi_gemm_desc* d, hipStream_t s, bool query);    // data gradients: the 352x256 form where whole rounds pay (0 = taken)
 void egomi_plan_tail_rows(int M, int N, int K, long long ws_bytes, int* rows, int* slices);
 int egomi_splitk_reduce_rows(void* C, int c_dtype, long long ldc, int rows, int N, const float* ws, int slices, int accumulate, hipStream_t s);
@@ -391,6 +392,12 @@ extern "C" int egomi_gemm_tn_kernel_id(const egomi_gemm_desc* d) { return (d && 
 int egomi_gemm_tn_try(const egomi_gemm_desc* d, hipStream_t s) {
     if (!tn_applicable(d)) return 1;
     { const int rc = egomi_tall_kmajor_try(d, s, false); if (rc <= 0) return rc; }
+    return egomi_gemm_tn_rest(d, s);
+}
+
+// this file's 256x256 kernel (also the second part of a product whose first columns took the 352x256 form: gemm_fast.hip egomi_tall_kmajor_try)
+int egomi_gemm_tn_rest(const egomi_gemm_desc* d, hipStream_t s) {
+    if (!tn_applicable(d)) return EGOMI_E_UNSUPPORTED;
     TnArgs g;
     g.A = (const bf16_t*)d->A; g.B = (const bf16_t*)d->B; g.C = d->C;
     g.M = d->M; g.N = d->N; g.K = d->K; g.lda = d->lda; g.ldb = d->ldb; g.ldc = d->ldc; g.accumulate = d->accumulate;

@@ -71,7 +71,14 @@ def test_k_major_products_slice_the_ragged_last_round():
     for K in (4096, 12288, 22016):                                         # o_proj, [Wq;Wk;Wv], [Wgate;Wup] data gradients
         d = tn_desc(5536, 4096, K, 0)
         assert L.egomi_gemm_kernel_id(ctypes.byref(d)) == 3
-        assert L.egomi_gemm_tn_tail_plan(ctypes.byref(d), ctypes.byref(row0), ctypes.byref(sl)) == 0
+        # round 4: by default these take the 352x256 form (16 x 16 tiles = one whole round): no K-sliced rows at all ...
+        assert L.egomi_gemm_tn_tail_plan(ctypes.byref(d), ctypes.byref(row0), ctypes.byref(sl)) == 0 and sl.value == 0 and row0.value == 5536
+        # ... and with that form switched off the k-major kernel's own 256x256 tiles slice their last rows
+        assert L.egomi_gemm_set_tall(0) == 0
+        try:
+            assert L.egomi_gemm_tn_tail_plan(ctypes.byref(d), ctypes.byref(row0), ctypes.byref(sl)) == 0
+        finally:
+            L.egomi_gemm_set_tall(-1)
         assert sl.value >= 2 and row0.value % 256 == 0 and 0 <= row0.value < 5536, (K, row0.value, sl.value)
         assert (K // 64) // sl.value >= 8
         assert (5536 - row0.value) * 4096 * 4 * sl.value <= d.workspace_bytes - 4096
