@@ -310,6 +310,8 @@ def main():
         model.train()
         opt = EgoAdamW(model, lr=2e-5)
         sync = GradSync(wire_dtype=torch.bfloat16, run_single=a.force_dist, resident=True) if (world > 1 or a.force_dist) else None      # large fp32 gradient buffers cross xGMI as bf16
+        if sync is None and mode == "unfrozen" and os.environ.get("EGOMI_BF16_GRADS", "1") != "0":
+            sync = GradSync(wire_dtype=torch.bfloat16, resident=True, local=True)     # one rank: the decoder layers' weight gradients in bf16 wire buffers, as a DP job (and the reference's bf16 engine) has them
         if sync is not None:
             sync.time_exposed = True
         model.engine.grad_sync = sync
@@ -346,7 +348,7 @@ def main():
             if check and int(cnt.min()) < N:
                 raise RuntimeError("synthetic clip has too few valid pixels")
             pc = ops.pc_norm(pts, col)                                                                            # A2
-            if EARLY_OPT and sync is None:
+            if EARLY_OPT and (sync is None or sync.local):
                 opt.arm(grad_scale=1.0)                                       # trainable decoder layers: AdamW under the backward pass of the layers below (one rank)
             loss = model.loss_and_backward(toks, masks, pc, Lp, dims.tok.pad, fps_start=fps_start)                # A3-A15
             if sync is not None:
@@ -428,6 +430,8 @@ def main():
         gs = dict(sync.stats)
         gs["exposed_ms_per_step"] = None if sync.exposed_ms() is None else round(sync.exposed_ms(), 3)     # compute stream waiting in GradSync.finish()
         gs["exposed_is"] = "mean HIP-event time the compute stream waits for the exchange's side stream before AdamW (last bucket's tail)"
+        if sync.local:
+            gs["local"] = "one rank, nothing exchanged: the decoder layers' weight gradients are produced in bf16 wire buffers and read there by AdamW (GradSync(local=True))"
     out = {
         "metric": "clips/sec/GPU (8-frame 224^2, 16-token text) fwd+bwd",
         "value": round(clips_total / dt, 4), "unit": "clips/s",
@@ -484,7 +488,7 @@ def main():
             dtu, psu, lossu, _, _ = measure(mu, ou, su, 10, 3, None, None)
             flu = flops_per_sample(dims, S, S - Lp, frozen_llm=False)
             cu = 10 * B / dtu
-            extra["unfrozen"] = {"workload": "configs[1] with --unfreeze_language_model (every LLM weight trained: wgrads + 6.7 B-parameter AdamW)", "steps": 10, "warmup": 3,
+            extra["unfrozen"] = {"workload": "configs[1] with --unfreeze_language_model (every LLM weight trained: wgrads + 6.7 B-parameter AdamW; overlapped optimizer step with per-layer updates under the backward pass, bf16 weight gradients in per-layer wire buffers as on the DP wire — GradSync(local=True); EGOMI_BF16_GRADS=0 / EGOMI_OPT_EARLY=0 switch them off)", "steps": 10, "warmup": 3,
                                  "ms_per_step": round(dtu / 10 * 1e3, 3), "clips_per_s": round(cu, 3), "algorithmic_tflop_per_clip": round(flu["fwd_bwd"] / 1e12, 3),
                                  "frac_of_peak": round(flu["fwd_bwd"] * cu / 1e12 / PEAK_BF16_TFLOPS, 4), "loss": round(lossu, 4),
                                  "formula": "frac_of_peak = algorithmic fwd+bwd FLOP per clip (3x forward for the LLM, SURVEY.md §8d) x clips/s / 2.5 PFLOP/s (whole step, not one kernel)"}

@@ -72,7 +72,7 @@ class GradSync:
     reduced on a side stream as soon as they close; `finish()` joins.  wire_dtype=torch.bfloat16: buckets of at least
     `wire_min_bytes` cross the fabric as bf16 with fp32 accumulation (see the module docstring)."""
 
-    def __init__(self, group=None, wire_dtype=None, wire_min_bytes=32 << 20, bucket_bytes=256 << 20, run_single=False, resident=False):
+    def __init__(self, group=None, wire_dtype=None, wire_min_bytes=32 << 20, bucket_bytes=256 << 20, run_single=False, resident=False, local=False):
         """bucket_bytes: loose tensors are packed until the open bucket reaches this size.  256 MB: in frozen-LLM mode the lm_head
         gradient (0.53 GB, final at the very START of backward) closes its own bucket at once and crosses the fabric under the 32
         layers' backward; with 1 GB it sat in the open bucket until the embedding gradient arrived at the end of backward and
@@ -82,6 +82,10 @@ class GradSync:
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.skip = self.world == 1 and not (run_single and dist.is_initialized())
+        # local=True on ONE rank (no process group): nothing is exchanged, but with resident=True the decoder layers' weight gradients are still
+        # produced in wire precision inside per-layer wire buffers and read there by EgoAdamW — the same bf16 gradients a multi-rank job trains on
+        # (and the reference's DeepSpeed bf16 engine: bf16 gradients, fp32 masters, train.py:92-104), 8 B per parameter less through HBM per step.
+        self.local = bool(local) and self.skip
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.stream = None
         self.wire_dtype, self.wire_min_bytes, self.bucket_bytes = wire_dtype, wire_min_bytes, bucket_bytes
@@ -123,7 +127,7 @@ class GradSync:
     def resident_wire(self, tag, n, device):
         """The persistent wire buffer [W * c] of bucket `tag` holding n elements (pad zero), or None when the bucket would not travel
         in wire_dtype (too small / resident mode off / nothing to exchange)."""
-        if self.skip or not self.resident or n * 4 < self.wire_min_bytes:
+        if (self.skip and not self.local) or not self.resident or n * 4 < self.wire_min_bytes:
             return None
         W = self.world
         c = -(-n // (W * 8)) * 8
@@ -135,6 +139,8 @@ class GradSync:
     def ready_resident(self, tag, wire):
         """`wire` (resident_wire(tag, ...)) holds this rank's gradients in wire precision: exchanged in place; afterwards it holds the sum
         over ranks, for the optimizer to read."""
+        if self.skip:                                  # local mode: one rank, the wire buffer already holds the sum
+            return
         self.flush()
         self._bucket_id += 1
         W, cuda = self.world, wire.is_cuda

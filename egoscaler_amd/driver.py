@@ -225,6 +225,8 @@ def train(args, model, train_data, val_data=None, device="cuda", log=print, step
     micro = micro_batch_per_rank(args.bs, accum, world)
     opt = EgoAdamW(model, lr=float(args.lr_llm))
     sync = GradSync(wire_dtype=torch.bfloat16 if model.engine.dtype == torch.bfloat16 else None, resident=True) if world > 1 else None     # EgoAdamW reads the wire
+    if sync is None and model.engine.dtype == torch.bfloat16 and model.engine.any_layer_trainable and model.engine.device.type == "cuda":
+        sync = GradSync(wire_dtype=torch.bfloat16, resident=True, local=True)      # one rank, --unfreeze_language_model: bf16 weight gradients in per-layer wire buffers (dp.py), nothing exchanged
     start_epoch, global_step, best_ade = 0, 0, float("inf")
     os.makedirs(args.out_dir, exist_ok=True)
     latest = os.path.join(args.out_dir, "latest_model.pt")
@@ -270,7 +272,7 @@ def train(args, model, train_data, val_data=None, device="cuda", log=print, step
                 last = a == n_mb - 1
                 model.accumulate_grads = a > 0                                      # first micro-batch overwrites (optimizer.zero_grad(), train.py:159)
                 model.engine.grad_sync = sync if last else None                     # reduce once, after the last micro-batch
-                if last and sync is None:                                           # one rank: trainable decoder layers are updated under this backward pass
+                if last and (sync is None or sync.local):                           # one rank: trainable decoder layers are updated under this backward pass
                     opt.arm(grad_scale=1.0 / (n_mb * world), lr=linear_warmup_lr(float(args.lr_llm), global_step, total_steps))
                 loss = model.loss_and_backward(batch["tokens"], batch["attention_masks"], batch["pcrgbs"], batch["prompts"].shape[1],
                                                model.dims.tok.pad, fps_start=torch.zeros(len(idx), dtype=torch.int32, device=device))

@@ -108,9 +108,11 @@ class Engine:
         """A decoder layer's gradients are final: its flat block goes out as one bucket (bucketed per layer,
         reverse layer order, overlapped with the rest of backward).  Without an exchange (one rank) an armed optimizer may update the layer
         right away (EgoAdamW.arm: the update runs on its side stream under the backward of the layers below)."""
-        if self.grad_sync is None and self.layer_final_hook is not None:
-            self.layer_final_hook(l)
+        one_rank = self.grad_sync is None or getattr(self.grad_sync, "local", False)
+        hook = self.layer_final_hook if one_rank else None
         if self.grad_sync is None or l not in self.layer_flat:
+            if hook is not None:
+                hook(l)
             return
         if self._direct is not None:
             wire, views = self._direct
@@ -123,9 +125,12 @@ class Engine:
                 self.reduced_grad[n] = v
             self._direct, self._direct_done = None, set()
             self.grad_sync.ready_resident(f"layer{l}", wire)
+            if hook is not None:                                         # (local mode: the optimizer reads the wire buffer right away)
+                hook(l)
             return
         self.grad_sync.ready_flat(f"layer{l}", self.layer_flat[l])
-
+        if hook is not None:
+            hook(l)
     def _begin_direct(self, l):
         """Resident exchange: this layer's weight gradients are produced in wire precision inside the layer's wire buffer (dp.py).  Only
         where every gradient of the layer is overwritten by this backward (no accumulation over micro-batches) on the bf16 k-major route."""

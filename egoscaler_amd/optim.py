@@ -27,7 +27,7 @@ class EgoAdamW:
         eng = self.model.engine
         self._armed = None
         eng.layer_final_hook = None
-        if eng.grad_sync is not None or eng.device.type != "cuda" or not eng.any_layer_trainable:
+        if (eng.grad_sync is not None and not getattr(eng.grad_sync, "local", False)) or eng.device.type != "cuda" or not eng.any_layer_trainable:
             return False
         if any(nm in eng.trainable for nm in getattr(eng, "wT", {})):      # (EGOMI_GEMM_TN=0 route; before the first forward pass the hook looks again)
             return False

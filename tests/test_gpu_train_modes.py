@@ -273,3 +273,39 @@ def test_zero_grad_after_an_overlapped_step_waits_for_the_update(unfreeze):
     for n in oa["state"]:
         for part in ("master", "m", "v"):
             assert torch.equal(oa["state"][n][part], ob["state"][n][part]), (n, part)
+
+
+def test_local_bf16_wire_gradients_on_one_rank_train_like_the_fp32_buffers():
+    """dp.GradSync(resident=True, local=True) on ONE rank (round 4): no exchange, but every decoder layer's weight gradients are produced in bf16 inside
+    the layer's wire buffer and read there by EgoAdamW — what a DP job (tests/test_gpu_dp.py) and the reference's DeepSpeed bf16 engine train on — also
+    with the armed per-layer updates.  Three steps: the losses follow the fp32-gradient run closely (bf16 rounding of the gradients only), the wire
+    buffers were really used, and the weights moved."""
+    from egoscaler_amd.dp import GradSync
+    from egoscaler_amd.optim import EgoAdamW
+    dims = _dims()
+    toks, masks, Lp = synth.synth_batch(dims, 4, text_len=8, num_steps=4, max_traj_token=40)
+    pts = torch.stack([synth.synth_cloud(dims, i) for i in range(4)])
+    start = [0, 17, 3, 9]
+    res = {}
+    for local in (False, True):
+        m = _model(dims, True, torch.bfloat16)
+        m.train()
+        opt = EgoAdamW(m, lr=1e-3, weight_decay=0.01)
+        sync = GradSync(wire_dtype=torch.bfloat16, wire_min_bytes=1 << 10, resident=True, local=True) if local else None
+        m.engine.grad_sync = sync
+        losses, used = [], 0
+        for i in range(3):
+            assert opt.arm(grad_scale=1.0) is True
+            losses.append(float(m.loss_and_backward(toks.cuda(), masks.cuda(), pts.cuda(), Lp, dims.tok.pad, fps_start=start)))
+            used += sum(1 for v in m.engine.reduced_grad.values() if v.dtype == torch.bfloat16)
+            if sync is not None:
+                sync.finish()
+            opt.step(grad_scale=1.0, overlap=True)
+        assert (used > 0) == local, used
+        res[local] = (losses, {k: v.detach().float().clone() for k, v in m.state_dict().items() if "layers.0.mlp.down_proj" in k or "layers.1.self_attn.q_proj" in k})
+    (la, wa), (lb, wb) = res[False], res[True]
+    assert la[0] == lb[0]                                      # the first forward is the same computation
+    for x, y in zip(la, lb):
+        assert abs(x - y) <= 2e-2 * abs(x), (la, lb)
+    for k in wa:
+        assert float((wa[k] - wb[k]).abs().max()) <= 5e-2 * float(wa[k].abs().max()) and not torch.equal(wa[k], wb[k]), k
