@@ -494,6 +494,12 @@ def main():
                                  "formula": "frac_of_peak = algorithmic fwd+bwd FLOP per clip (3x forward for the LLM, SURVEY.md §8d) x clips/s / 2.5 PFLOP/s (whole step, not one kernel)"}
             del mu, ou, su
             torch.cuda.empty_cache()
+            mp, op_, sp = build("pc")                                            # --unfreeze_pc_encoder: point backbone trained (train-mode BatchNorm, DropPath), LLM frozen
+            dtp, _, lossp, _, _ = measure(mp, op_, sp, 10, 3, None, None)
+            extra["pc"] = {"workload": "configs[1] with --unfreeze_pc_encoder (point backbone in train() mode and trained, LLM frozen: model_arch.py:33-36)", "steps": 10, "warmup": 3,
+                           "ms_per_step": round(dtp / 10 * 1e3, 3), "clips_per_s": round(10 * B / dtp, 3), "loss": round(lossp, 4)}
+            del mp, op_, sp
+            torch.cuda.empty_cache()
         except Exception as e:                                                   # an extra leg never takes the headline down
             extra["error"] = f"{type(e).__name__}: {e}"
         extra["seconds"] = round(time.perf_counter() - t_x, 1)
