@@ -1197,30 +1197,31 @@ extern "C" int egomi_linear_smallk(const void* x, int x_dtype, const void* w, co
 }
 
 // column sums: out[c] += sum_r x[r, c]   (bias gradients of the projector, pointllm.py:67-81 backward).  DETERMINISTIC (round 4): one block
-// owns 32 columns over all rows (32 row-lanes), the partials meet in LDS in a fixed order; the row blocks of the earlier form met in `out`
-// with fp32 atomics.
+// owns 16 columns over all rows (64 row-lanes: lane rl adds rows rl, rl + 64, ... in increasing order), the 64 lane sums meet in LDS and are added in
+// lane order; the row blocks of the earlier form met in `out` with fp32 atomics.  (16-column strips: the bias gradients of the trainable point backbone
+// are [4104, 384 .. 1536] — 32-column strips gave 12 .. 48 blocks and 44 us per call.)
 template <typename T>
 __global__ __launch_bounds__(1024) void colsum_kernel(const T* x, long long R, int C, long long ld, float* out) {
-    __shared__ float red[32][33];
-    const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
-    const int c = blockIdx.x * 32 + cl;
+    __shared__ float red[64][17];
+    const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
     float acc = 0.f;
     if (c < C) {
 #pragma unroll 4
-        for (long long r = rl; r < R; r += 32) acc += Cvt<T>::ld(x + r * ld + c);
+        for (long long r = rl; r < R; r += 64) acc += Cvt<T>::ld(x + r * ld + c);
     }
     red[rl][cl] = acc;
     __syncthreads();
-    if (threadIdx.x < 32 && c < C) {
+    if (threadIdx.x < 16 && c < C) {
         float s = 0.f;
 #pragma unroll 8
-        for (int g = 0; g < 32; ++g) s += red[g][threadIdx.x];
+        for (int g = 0; g < 64; ++g) s += red[g][threadIdx.x];
         out[c] += s;
     }
 }
 extern "C" int egomi_colsum(const void* x, int64_t R, int C, int64_t ld, float* out, int dtype, egomi_stream_t stream) {
     if (!x || !out) return EGOMI_E_BADARG;
     if (R <= 0 || C <= 0 || ld < C) return EGOMI_E_SHAPE;
-    EGOMI_DISPATCH_DTYPE(dtype, EGOMI_LAUNCH(colsum_kernel<T>, dim3((C + 31) / 32), dim3(1024), 0, (hipStream_t)stream, (const T*)x, (long long)R, C, (long long)ld, out));
+    EGOMI_DISPATCH_DTYPE(dtype, EGOMI_LAUNCH(colsum_kernel<T>, dim3((C + 15) / 16), dim3(1024), 0, (hipStream_t)stream, (const T*)x, (long long)R, C, (long long)ld, out));
     return egomi_launch_status();
 }
