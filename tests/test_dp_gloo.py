@@ -53,7 +53,7 @@ def _worker(rank, world, port, q):
         want_noisy = acc.bfloat16().float()
         wire_ok = bool(torch.equal(layer, torch.full((1000,), 1.5)) and torch.equal(big, torch.full((64, 16), 0.75))
                        and torch.equal(small, torch.full((4,), 3.0)) and big.dtype == torch.float32 and torch.equal(noisy, want_noisy))
-        q.put((rank, lo, hi, {n: float(b[0, 0]) for n, b in bufs.items()}, sync.grad_scale, st1, wire_ok, dict(s2.stats), noisy.clone()))
+        q.put((rank, lo, hi, {n: float(b[0, 0]) for n, b in bufs.items()}, sync.grad_scale, st1, wire_ok, dict(s2.stats), noisy.numpy().copy()))      # numpy: pickled by value (a torch tensor travels by file descriptor and the producer may be gone before the parent reads it: ConnectionResetError, one run in four)
     finally:
         dist.destroy_process_group()
 
@@ -77,7 +77,7 @@ def test_grad_sync_world2_gloo():
         assert r[4] == 0.5 and r[5]["buckets"] == 1 and r[5]["collective_calls"] == 1          # three tensors, one fp32 all-reduce
         assert r[6], "bf16-wire buckets must equal the fp32-accumulated sum of bf16-rounded contributions"
         assert r[7]["buckets"] == 3 and r[7]["collective_calls"] == 2 + 2 + 1                  # wire buckets: all-to-all + all-gather
-    assert torch.equal(res[0][8], res[1][8])                             # replicas hold identical reduced values
+    assert (res[0][8] == res[1][8]).all()                                # replicas hold identical reduced values
 
 
 def _resident_worker(rank, world, port, q):
@@ -99,7 +99,7 @@ def _resident_worker(rank, world, port, q):
         same_buffer = s.resident_wire("layer0", n, torch.device("cpu")).data_ptr() == wire.data_ptr()       # persistent per tag
         too_small = s.resident_wire("tiny", 16, torch.device("cpu")) is None                                  # below wire_min_bytes: packed route
         off = GradSync(wire_dtype=torch.bfloat16, wire_min_bytes=1024).resident_wire("layer0", n, torch.device("cpu")) is None
-        q.put((rank, ok, same_buffer, too_small, off, dict(s.stats), wire.clone()))
+        q.put((rank, ok, same_buffer, too_small, off, dict(s.stats), wire.float().numpy().copy()))     # numpy: pickled by value
     finally:
         dist.destroy_process_group()
 
@@ -121,7 +121,7 @@ def test_resident_exchange_world2_gloo():
     for r in res:
         assert r[1] and r[2] and r[3] and r[4], r[:5]
         assert r[5]["buckets"] == 1 and r[5]["collective_calls"] == 2 and r[5]["resident_buckets"] == 1
-    assert torch.equal(res[0][6], res[1][6])
+    assert (res[0][6] == res[1][6]).all()
 
 
 def test_engine_host_logic_for_stacked_views_and_parameter_groups():
